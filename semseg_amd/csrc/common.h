@@ -1,0 +1,110 @@
+// Shared device/host helpers for the semseg_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdarg.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) float floatx2;
+typedef __attribute__((ext_vector_type(4))) float floatx4;
+typedef __attribute__((ext_vector_type(8))) float floatx8;
+typedef __attribute__((ext_vector_type(16))) float floatx16;
+
+#define SS_F32 0
+#define SS_BF16 1
+
+// ---------------------------------------------------------------- errors
+extern thread_local char ss_err_buf[512];
+int ss_fail(int code, const char* fmt, ...);
+#define SS_CHECK(cond, ...) do { if (!(cond)) return ss_fail(-1, __VA_ARGS__); } while (0)
+#define SS_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return ss_fail(-2, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+#define SS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) \
+    return ss_fail(-3, "kernel launch failed at %s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
+
+__host__ __device__ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---------------------------------------------------------------- element access
+template <typename T> struct VecOf;            // 16-byte vector of T
+template <> struct VecOf<float> { static constexpr int N = 4; typedef floatx4 type; };
+template <> struct VecOf<bf16> { static constexpr int N = 8; typedef bf16x8 type; };
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+
+// 8 consecutive elements as floats (the unit of work of the bandwidth kernels)
+struct F8 { float v[8]; };
+__device__ __forceinline__ F8 load8(const float* p) {
+    F8 r; floatx4 a = *(const floatx4*)p, b = *(const floatx4*)(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.v[i] = a[i]; r.v[4 + i] = b[i]; }
+    return r;
+}
+__device__ __forceinline__ F8 load8(const bf16* p) {
+    F8 r; bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
+    return r;
+}
+__device__ __forceinline__ void store8(float* p, const F8& r) {
+    floatx4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = r.v[i]; b[i] = r.v[4 + i]; }
+    *(floatx4*)p = a; *(floatx4*)(p + 4) = b;
+}
+__device__ __forceinline__ void store8(bf16* p, const F8& r) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16)r.v[i];
+    *(bf16x8*)p = a;
+}
+__device__ __forceinline__ F8 zero8() { F8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = 0.f;
+    return r; }
+
+// ---------------------------------------------------------------- wave helpers (wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float group_sum(float v, int lanes) {      // lanes: power of two <= 64
+    for (int o = lanes >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float group_max(float v, int lanes) {
+    for (int o = lanes >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+// Mish(x) = x * tanh(softplus(x)), softplus threshold 20 as torch
+__device__ __forceinline__ float mish_f(float x) {
+    float sp = x > 20.f ? x : log1pf(expf(x));
+    return x * tanhf(sp);
+}
+__device__ __forceinline__ float mish_grad(float x) {
+    float sp = x > 20.f ? x : log1pf(expf(x));
+    float t = tanhf(sp);
+    float sig = 1.f / (1.f + expf(-x));
+    return t + x * (1.f - t * t) * sig;
+}
+
+// dtype dispatch for extern "C" entry points
+#define SS_DISPATCH(dtype, ...) \
+    do { if ((dtype) == SS_F32) { typedef float T; __VA_ARGS__; } \
+         else if ((dtype) == SS_BF16) { typedef bf16 T; __VA_ARGS__; } \
+         else return ss_fail(-1, "unsupported dtype code %d", (int)(dtype)); } while (0)

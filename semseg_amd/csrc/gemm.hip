@@ -1,0 +1,298 @@
+// MFMA GEMM family for the 1x1 / linear projections.
+//
+//   ss_gemm_nt : C[M,N] = epilogue(A[M,K] . B[N,K]^T)            (forward, and dgrad with a transposed weight copy)
+//   ss_gemm_tn : C[M,N] (+)= sum_r A[r,M]^T . B[r,N]   (fp32 out)  (weight gradient; split over r, deterministic slab reduce)
+//
+// One kernel template serves both: 128 x BN x (128 bytes of K) tiles, 4 waves in a 2x2 grid, each wave
+// 2 x (BN/64) MFMA tiles of 32x32.  bf16 uses v_mfma_f32_32x32x16_bf16; fp32 uses eight v_mfma_f32_32x32x2_f32
+// per 16-deep k-step with the SAME fragment layout (lane (i,h) holds k = 8h..8h+7), so both dtypes share every
+// line of tiling code.  Operands are staged global -> registers -> LDS (rows padded by 16 B: conflict-free
+// ds_read_b128), with the next tile's global loads in flight under the current tile's MFMAs.
+#include "common.h"
+
+__device__ __forceinline__ floatx16 mma32(bf16x8 a, bf16x8 b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ floatx16 mma32(floatx8 a, floatx8 b, floatx16 c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}
+
+__device__ __forceinline__ bf16x8 ldfrag(const bf16* p) { return *(const bf16x8*)p; }
+__device__ __forceinline__ floatx8 ldfrag(const float* p) {
+    floatx4 a = *(const floatx4*)p, b = *(const floatx4*)(p + 4);
+    floatx8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = a[i]; r[4 + i] = b[i]; }
+    return r;
+}
+
+template <typename T> struct GemmT;
+template <> struct GemmT<bf16> { typedef bf16x8 frag; typedef bf16x8 vec; static constexpr int BK = 64, VEC = 8; };
+template <> struct GemmT<float> { typedef floatx8 frag; typedef floatx4 vec; static constexpr int BK = 32, VEC = 4; };
+
+struct GemmParams {
+    const void* A; const void* B; void* C;
+    int64_t M; int N; int64_t K;          // TRANS: K = number of reduction rows R
+    int64_t lda, ldb, ldc;
+    const float* bias;
+    const void* res; int64_t ldr;
+    const float* rowscale; int64_t rows_per_scale;
+    int act;                               // 0 none, 1 GELU(erf)
+    int vecA, vecB;                        // 16-byte vector loads allowed
+    int64_t k_per_split;                   // TRANS: reduction rows per blockIdx.z
+};
+
+template <typename T, typename TC, int BN, bool TRANS>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+    typedef GemmT<T> G;
+    typedef typename G::frag frag;
+    typedef typename G::vec vec;
+    constexpr int BM = 128, BK = G::BK, VEC = G::VEC;
+    constexpr int LDK = BK + VEC;                 // NT image: [row][k], rows padded by 16 B
+    constexpr int LDMA = BM + VEC, LDMB = BN + VEC;   // TRANS image: [k][row]
+    constexpr int A_ELEMS = TRANS ? BK * LDMA : BM * LDK;
+    constexpr int B_ELEMS = TRANS ? BK * LDMB : BN * LDK;
+    constexpr int NA = BM * BK / VEC / 256, NB = BN * BK / VEC / 256;   // 16-B chunks per thread
+    constexpr int TM = 2, TN = BN / 64;
+    __shared__ __attribute__((aligned(16))) T As[A_ELEMS];
+    __shared__ __attribute__((aligned(16))) T Bs[B_ELEMS];
+
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ B = (const T*)p.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ntiles_n = (p.N + BN - 1) / BN;            // n-tile fastest: the blocks sharing an A panel run together
+    const int64_t m0 = (int64_t)(blockIdx.x / ntiles_n) * BM;
+    const int n0 = (int)(blockIdx.x % ntiles_n) * BN;
+    int64_t kbeg = 0, kend = p.K;
+    if (TRANS) { kbeg = (int64_t)blockIdx.z * p.k_per_split; kend = min(p.K, kbeg + p.k_per_split); }
+
+    vec ra[NA], rb[NB];
+    auto gload = [&](int64_t k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int c = tid + i * 256;
+            int64_t row, col; bool ok;            // row: leading index in memory, col: contiguous index
+            if (TRANS) { int r = c / (BM / VEC), mc = c % (BM / VEC); row = k0 + r; col = m0 + mc * VEC; ok = row < kend && col < p.M; }
+            else { int r = c / (BK / VEC), kc = c % (BK / VEC); row = m0 + r; col = k0 + kc * VEC; ok = row < p.M && col < kend; }
+            vec v;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
+            if (ok) {
+                const T* src = A + row * p.lda + col;
+                if (p.vecA) v = *(const vec*)src;
+                else { int64_t lim = TRANS ? p.M : kend;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) if (col + e < lim) v[e] = src[e]; }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int c = tid + i * 256;
+            int64_t row, col; bool ok;
+            if (TRANS) { int r = c / (BN / VEC), nc = c % (BN / VEC); row = k0 + r; col = n0 + nc * VEC; ok = row < kend && col < p.N; }
+            else { int r = c / (BK / VEC), kc = c % (BK / VEC); row = n0 + r; col = k0 + kc * VEC; ok = row < p.N && col < kend; }
+            vec v;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
+            if (ok) {
+                const T* src = B + row * p.ldb + col;
+                if (p.vecB) v = *(const vec*)src;
+                else { int64_t lim = TRANS ? (int64_t)p.N : kend;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) if (col + e < lim) v[e] = src[e]; }
+            }
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int c = tid + i * 256;
+            if (TRANS) { int r = c / (BM / VEC), mc = c % (BM / VEC); *(vec*)&As[r * LDMA + mc * VEC] = ra[i]; }
+            else { int r = c / (BK / VEC), kc = c % (BK / VEC); *(vec*)&As[r * LDK + kc * VEC] = ra[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int c = tid + i * 256;
+            if (TRANS) { int r = c / (BN / VEC), nc = c % (BN / VEC); *(vec*)&Bs[r * LDMB + nc * VEC] = rb[i]; }
+            else { int r = c / (BK / VEC), kc = c % (BK / VEC); *(vec*)&Bs[r * LDK + kc * VEC] = rb[i]; }
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (kbeg < kend) {
+        gload(kbeg);
+        lstore();
+        __syncthreads();
+        for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+            const bool more = k0 + BK < kend;
+            if (more) gload(k0 + BK);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                frag fa[TM], fb[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    int row = wm * 64 + a * 32 + li;
+                    if (TRANS) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) fa[a][e] = As[(ks * 16 + lh * 8 + e) * LDMA + row];
+                    } else fa[a] = ldfrag(&As[row * LDK + ks * 16 + lh * 8]);
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    int row = wn * (BN / 2) + b * 32 + li;
+                    if (TRANS) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) fb[b][e] = Bs[(ks * 16 + lh * 8 + e) * LDMB + row];
+                    } else fb[b] = ldfrag(&Bs[row * LDK + ks * 16 + lh * 8]);
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[a][b] = mma32(fa[a], fb[b], acc[a][b]);
+            }
+            __syncthreads();
+            if (more) { lstore(); __syncthreads(); }
+        }
+    }
+
+    // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    TC* __restrict__ C = (TC*)p.C;
+    if (TRANS) C += (int64_t)blockIdx.z * p.M * p.N;
+    const TC* __restrict__ R = (const TC*)p.res;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            int col = n0 + wn * (BN / 2) + b * 32 + li;
+            if (col >= p.N) continue;
+            float bv = (!TRANS && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int64_t row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= p.M) continue;
+                float v = acc[a][b][r];
+                if (!TRANS) {
+                    v += bv;
+                    if (p.act == 1) v = gelu_erf(v);
+                    if (p.rowscale) v *= p.rowscale[row / p.rows_per_scale];
+                    if (R) v += to_f(R[row * p.ldr + col]);
+                }
+                C[row * p.ldc + col] = from_f<TC>(v);
+            }
+        }
+}
+
+// sum nsplit dense [n] fp32 slabs into out (row-major MxN with leading dimension ldc)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit, int64_t M, int N, float* __restrict__ out,
+                                    int64_t ldc, int accumulate) {
+    int64_t n = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += slabs[(int64_t)z * n + i];
+        int64_t o = (i / N) * ldc + (i % N);
+        out[o] = accumulate ? out[o] + s : s;
+    }
+}
+
+template <typename T, typename TC>
+static int launch_nt(const GemmParams& p, hipStream_t st) {
+    dim3 block(256);
+    if (p.N <= 64) {
+        dim3 grid((unsigned)(cdiv(p.N, 64) * cdiv(p.M, 128)), 1, 1);
+        hipLaunchKernelGGL((gemm_kernel<T, TC, 64, false>), grid, block, 0, st, p);
+    } else {
+        dim3 grid((unsigned)(cdiv(p.N, 128) * cdiv(p.M, 128)), 1, 1);
+        hipLaunchKernelGGL((gemm_kernel<T, TC, 128, false>), grid, block, 0, st, p);
+    }
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                          int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldr,
+                          const float* rowscale, int64_t rows_per_scale, int act, hipStream_t stream) {
+    SS_CHECK(A && B && C, "ss_gemm_nt: null operand");
+    SS_CHECK(M > 0 && N > 0 && K > 0 && N < (1 << 30), "ss_gemm_nt: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+    SS_CHECK(lda >= K && ldb >= K && ldc >= N, "ss_gemm_nt: leading dimension smaller than the row");
+    SS_CHECK(!res || ldr >= N, "ss_gemm_nt: bad ldr");
+    SS_CHECK(!rowscale || rows_per_scale > 0, "ss_gemm_nt: rows_per_scale must be > 0");
+    SS_CHECK(cdiv(M, 128) * cdiv(N, 64) < 2147483647LL, "ss_gemm_nt: too many tiles");
+    GemmParams p{};
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = (int)N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.bias = bias; p.res = res; p.ldr = ldr; p.rowscale = rowscale; p.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+    p.act = act; p.k_per_split = K;
+    int vec = dtype == SS_BF16 ? 8 : 4;
+    p.vecA = aligned16(A) && lda % vec == 0 && K % vec == 0;
+    p.vecB = aligned16(B) && ldb % vec == 0 && K % vec == 0;
+    if (dtype == SS_F32) return launch_nt<float, float>(p, stream);
+    if (dtype == SS_BF16) return out_f32 ? launch_nt<bf16, float>(p, stream) : launch_nt<bf16, bf16>(p, stream);
+    return ss_fail(-1, "ss_gemm_nt: unsupported dtype %d", dtype);
+}
+
+static void tn_plan(int64_t M, int64_t N, int64_t R, int bk, int* nsplit, int64_t* rps) {
+    int64_t tiles = cdiv(M, 128) * cdiv(N, N <= 64 ? 64 : 128);
+    int64_t want = cdiv(2048, tiles);                       // ~8 workgroups per CU
+    int64_t maxs = cdiv(R, 4 * bk);                          // at least 4 k-tiles per split
+    int64_t s = want < 1 ? 1 : want;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    int64_t per = cdiv(cdiv(R, s), bk) * bk;
+    *rps = per;
+    *nsplit = (int)cdiv(R, per);
+}
+
+extern "C" int64_t ss_gemm_tn_workspace(int dtype, int64_t M, int64_t N, int64_t R) {
+    int ns; int64_t rps;
+    tn_plan(M, N, R, dtype == SS_BF16 ? 64 : 32, &ns, &rps);
+    return (int64_t)ns * M * N * (int64_t)sizeof(float);
+}
+
+extern "C" int ss_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                          int64_t M, int64_t N, int64_t R, void* workspace, int64_t ws_bytes, int accumulate, hipStream_t stream) {
+    SS_CHECK(A && B && C && workspace, "ss_gemm_tn: null operand");
+    SS_CHECK(M > 0 && N > 0 && R > 0 && N < (1 << 30) && M < (1 << 30), "ss_gemm_tn: bad shape");
+    SS_CHECK(lda >= M && ldb >= N && ldc >= N, "ss_gemm_tn: leading dimension smaller than the row");
+    int ns; int64_t rps;
+    int bk = dtype == SS_BF16 ? 64 : 32;
+    tn_plan(M, N, R, bk, &ns, &rps);
+    SS_CHECK(ws_bytes >= (int64_t)ns * M * N * 4, "ss_gemm_tn: workspace too small (%lld < %lld)", (long long)ws_bytes,
+             (long long)((int64_t)ns * M * N * 4));
+    GemmParams p{};
+    p.A = A; p.B = B; p.C = workspace; p.M = M; p.N = (int)N; p.K = R; p.lda = lda; p.ldb = ldb; p.ldc = N;
+    p.k_per_split = rps;
+    int vec = dtype == SS_BF16 ? 8 : 4;
+    p.vecA = aligned16(A) && lda % vec == 0 && M % vec == 0;
+    p.vecB = aligned16(B) && ldb % vec == 0 && N % vec == 0;
+    dim3 block(256);
+    if (N <= 64) {
+        dim3 grid((unsigned)(cdiv(N, 64) * cdiv(M, 128)), 1, ns);
+        if (dtype == SS_F32) hipLaunchKernelGGL((gemm_kernel<float, float, 64, true>), grid, block, 0, stream, p);
+        else if (dtype == SS_BF16) hipLaunchKernelGGL((gemm_kernel<bf16, float, 64, true>), grid, block, 0, stream, p);
+        else return ss_fail(-1, "ss_gemm_tn: unsupported dtype %d", dtype);
+    } else {
+        dim3 grid((unsigned)(cdiv(N, 128) * cdiv(M, 128)), 1, ns);
+        if (dtype == SS_F32) hipLaunchKernelGGL((gemm_kernel<float, float, 128, true>), grid, block, 0, stream, p);
+        else if (dtype == SS_BF16) hipLaunchKernelGGL((gemm_kernel<bf16, float, 128, true>), grid, block, 0, stream, p);
+        else return ss_fail(-1, "ss_gemm_tn: unsupported dtype %d", dtype);
+    }
+    SS_LAUNCH_CHECK();
+    int64_t n = M * N;
+    int rb = (int)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rb), dim3(256), 0, stream, (const float*)workspace, ns, M, (int)N, C, ldc, accumulate);
+    SS_LAUNCH_CHECK();
+    return 0;
+}

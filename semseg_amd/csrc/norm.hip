@@ -1,0 +1,360 @@
+// LayerNorm (token layout) and BatchNorm2d (channels-last) forward/backward, bias-gradient
+// column sums and per-image average pooling (K14).  All bandwidth-bound: 16-byte channel-contiguous accesses,
+// fp32 statistics, deterministic reductions (colreduce.h).
+#include "common.h"
+#include "colreduce.h"
+
+// ------------------------------------------------------------------ LayerNorm
+// One row is handled by `lpr` lanes (power of two), NCH chunks of 8 channels per lane.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+        const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+        int64_t rows, int C, int lpr, float eps) {
+    const int lane = threadIdx.x & 63, lig = lane & (lpr - 1), rpw = 64 / lpr;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r0 = wave * rpw; r0 < rows; r0 += nwaves * rpw) {
+        const int64_t r = r0 + lane / lpr;
+        const bool rok = r < rows;
+        F8 v[NCH]; float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int c = (lig + j * lpr) * 8;
+            if (rok && c < C) { v[j] = load8(x + r * C + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[j].v[e]; }
+            else v[j] = zero8();
+        }
+        const float mu = group_sum(s, lpr) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int c = (lig + j * lpr) * 8;
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float d = v[j].v[e] - mu; q += d * d; } }
+        }
+        const float rs = rsqrtf(group_sum(q, lpr) / C + eps);
+        if (!rok) continue;
+        if (lig == 0) { mean[r] = mu; rstd[r] = rs; }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int c = (lig + j * lpr) * 8;
+            if (c < C) {
+                F8 g = load8(gamma + c), b = load8(beta + c), o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.v[e] = (v[j].v[e] - mu) * rs * g.v[e] + b.v[e];
+                store8(y + r * C + c, o);
+            }
+        }
+    }
+}
+
+// dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat));  per-block partials of dgamma = sum dy*xhat, dbeta = sum dy
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+        const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+        T* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C, int lpr) {
+    extern __shared__ float sh[];                 // [groups][2][C]
+    const int lane = threadIdx.x & 63, lig = lane & (lpr - 1), rpw = 64 / lpr;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float dg[NCH][8], db[NCH][8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; }
+    for (int64_t r0 = wave * rpw; r0 < rows; r0 += nwaves * rpw) {
+        const int64_t r = r0 + lane / lpr;
+        const bool rok = r < rows;
+        const float mu = rok ? mean[r] : 0.f, rs = rok ? rstd[r] : 0.f;
+        F8 xh[NCH], gy[NCH]; float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int c = (lig + j * lpr) * 8;
+            if (rok && c < C) {
+                F8 xv = load8(x + r * C + c), dv = load8(dy + r * C + c), g = load8(gamma + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float h = (xv.v[e] - mu) * rs;
+                    dg[j][e] += dv.v[e] * h; db[j][e] += dv.v[e];
+                    float t = dv.v[e] * g.v[e];
+                    xh[j].v[e] = h; gy[j].v[e] = t; s1 += t; s2 += t * h;
+                }
+            } else { xh[j] = zero8(); gy[j] = zero8(); }
+        }
+        s1 = group_sum(s1, lpr) / C; s2 = group_sum(s2, lpr) / C;
+        if (!rok) continue;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int c = (lig + j * lpr) * 8;
+            if (c < C) { F8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.v[e] = rs * (gy[j].v[e] - s1 - xh[j].v[e] * s2);
+                store8(dx + r * C + c, o); }
+        }
+    }
+    // fixed-order block reduction of the per-lane column partials
+    const int groups = (blockDim.x >> 6) * rpw, grp = (threadIdx.x >> 6) * rpw + lane / lpr;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        int c = (lig + j * lpr) * 8;
+        if (c < C)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sh[(grp * 2 + 0) * C + c + e] = dg[j][e]; sh[(grp * 2 + 1) * C + c + e] = db[j][e]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float s = 0.f;
+        for (int g = 0; g < groups; ++g) s += sh[g * 2 * C + i];
+        partial[(int64_t)blockIdx.x * 2 * C + i] = s;
+    }
+}
+
+static int ln_geom(int C, int* lpr, int* nch) {
+    int chunks = C / 8, l = 1;
+    while (l < chunks && l < 64) l <<= 1;
+    *lpr = l; *nch = (int)cdiv(chunks, l);
+    return (C % 8 == 0 && *nch <= 2) ? 0 : -1;
+}
+
+extern "C" int ss_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                float* rstd, int64_t rows, int C, float eps, hipStream_t stream) {
+    int lpr, nch;
+    SS_CHECK(x && gamma && beta && y && mean && rstd && rows > 0, "ss_layernorm_fwd: bad arguments");
+    SS_CHECK(ln_geom(C, &lpr, &nch) == 0, "ss_layernorm_fwd: C=%d must be a multiple of 8 and <= 1024", C);
+    int64_t waves = cdiv(rows, 64 / lpr);
+    int blocks = (int)(cdiv(waves, 4) < 4096 ? cdiv(waves, 4) : 4096);
+    SS_DISPATCH(dtype, {
+        if (nch == 1) hipLaunchKernelGGL((layernorm_fwd_kernel<T, 1>), dim3(blocks), dim3(256), 0, stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, lpr, eps);
+        else hipLaunchKernelGGL((layernorm_fwd_kernel<T, 2>), dim3(blocks), dim3(256), 0, stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, lpr, eps);
+    });
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// workspace: SS_LN_BWD_BLOCKS * 2 * C floats
+#define SS_LN_BWD_BLOCKS 1024
+extern "C" int ss_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                void* dx, float* dgamma, float* dbeta, int64_t rows, int C, float* workspace, int64_t ws_bytes,
+                                hipStream_t stream) {
+    int lpr, nch;
+    SS_CHECK(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && rows > 0, "ss_layernorm_bwd: bad arguments");
+    SS_CHECK(ln_geom(C, &lpr, &nch) == 0, "ss_layernorm_bwd: C=%d must be a multiple of 8 and <= 1024", C);
+    SS_CHECK(dbeta == dgamma + C, "ss_layernorm_bwd: dgamma/dbeta must be one [2,C] buffer");
+    int64_t waves = cdiv(rows, 64 / lpr);
+    int blocks = (int)(cdiv(waves, 4) < SS_LN_BWD_BLOCKS ? cdiv(waves, 4) : SS_LN_BWD_BLOCKS);
+    SS_CHECK(ws_bytes >= (int64_t)blocks * 2 * C * 4, "ss_layernorm_bwd: workspace too small");
+    size_t shm = (size_t)4 * (64 / lpr) * 2 * C * sizeof(float);
+    SS_DISPATCH(dtype, {
+        if (nch == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 1>), dim3(blocks), dim3(256), shm, stream, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, workspace, rows, C, lpr);
+        else hipLaunchKernelGGL((layernorm_bwd_kernel<T, 2>), dim3(blocks), dim3(256), shm, stream, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, workspace, rows, C, lpr);
+    });
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(2 * C, 256), 1), dim3(256), 0, stream, workspace, blocks, 2 * C, 1.f, dgamma, 0);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients, per-image pooling)
+template <typename T> struct ColSumF {
+    static constexpr int K = 1;
+    const T* x; int64_t ld;
+    __device__ void operator()(int64_t row, int c0, float (&acc)[1][8]) const {
+        F8 v = load8(x + row * ld + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[0][e] += v.v[e];
+    }
+};
+
+// out[g][c] (+)= scale * sum_{r < rows} x[g*rows + r][c]      (groups = images for average pooling, 1 for bias gradients)
+extern "C" int ss_colsum(int dtype, const void* x, int64_t ld, int64_t rows, int C, int groups, float scale, float* out,
+                         int accumulate, float* workspace, int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(x && out && workspace && rows > 0 && groups > 0 && C > 0 && C % 8 == 0 && ld >= C && ld % 8 == 0, "ss_colsum: bad arguments (C=%d)", C);
+    ColGeom g = col_geom(rows, C);
+    SS_CHECK(ws_bytes >= (int64_t)groups * g.nb * C * 4, "ss_colsum: workspace too small");
+    SS_DISPATCH(dtype, {
+        ColSumF<T> f{(const T*)x, ld};
+        hipLaunchKernelGGL((colreduce_partial_kernel<ColSumF<T>>), dim3(g.nb, groups), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
+    });
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(C, 256), groups), dim3(256), 0, stream, workspace, g.nb, C, scale, out, accumulate);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ BatchNorm2d on [rows, C]
+template <typename T> struct BnStatF {
+    static constexpr int K = 2;
+    const T* x; int64_t ld;
+    __device__ void operator()(int64_t row, int c0, float (&acc)[2][8]) const {
+        F8 v = load8(x + row * ld + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[0][e] += v.v[e]; acc[1][e] += v.v[e] * v.v[e]; }
+    }
+};
+
+// stats[0][c] = mean, stats[1][c] = rstd (biased variance); running stats updated like nn.BatchNorm2d (unbiased var)
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nb, int C, int64_t n, float eps, float momentum,
+                                   float* __restrict__ stats, float* running_mean, float* running_var, int64_t* nbt) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nb; ++b) { s += partial[((int64_t)b * 2 + 0) * C + c]; q += partial[((int64_t)b * 2 + 1) * C + c]; }
+    double mu = s / (double)n, var = q / (double)n - mu * mu;
+    if (var < 0) var = 0;
+    stats[c] = (float)mu;
+    stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+extern "C" int ss_bn_stats(int dtype, const void* x, int64_t ld, int64_t rows, int C, float eps, float momentum, float* stats,
+                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* workspace,
+                           int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(x && stats && workspace && rows > 0 && C > 0 && C % 8 == 0 && ld >= C && ld % 8 == 0, "ss_bn_stats: bad arguments (C=%d)", C);
+    ColGeom g = col_geom(rows, C);
+    SS_CHECK(ws_bytes >= (int64_t)g.nb * 2 * C * 4, "ss_bn_stats: workspace too small");
+    SS_DISPATCH(dtype, {
+        BnStatF<T> f{(const T*)x, ld};
+        hipLaunchKernelGGL((colreduce_partial_kernel<BnStatF<T>>), dim3(g.nb, 1), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
+    });
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, workspace, g.nb, C, rows, eps, momentum,
+                       stats, running_mean, running_var, num_batches_tracked);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// eval mode: stats from running buffers
+__global__ void bn_eval_stats_kernel(const float* rm, const float* rv, int C, float eps, float* stats) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { stats[c] = rm[c]; stats[C + c] = rsqrtf(rv[c] + eps); }
+}
+extern "C" int ss_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* stats, hipStream_t stream) {
+    SS_CHECK(running_mean && running_var && stats && C > 0, "ss_bn_eval_stats: bad arguments");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, running_mean, running_var, C, eps, stats);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// y[r] = res[r] + mask[b,c] * act(gamma * (z - mean) * rstd + beta);   act: 0 none, 1 Mish
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, int64_t ldz, const float* __restrict__ stats,
+        const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, int64_t ldr,
+        const float* __restrict__ mask, int64_t rows_per_image, T* __restrict__ y, int64_t ldy, int64_t rows, int C, int act) {
+    const int chunks = C / 8;
+    const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks; const int c = (int)(i % chunks) * 8;
+        F8 v = load8(z + r * ldz + c), mu = load8(stats + c), rs = load8(stats + C + c), g = load8(gamma + c), b = load8(beta + c), o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float u = (v.v[e] - mu.v[e]) * rs.v[e] * g.v[e] + b.v[e];
+            o.v[e] = act == 1 ? mish_f(u) : u;
+        }
+        if (mask) { F8 m = load8(mask + (r / rows_per_image) * C + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] *= m.v[e]; }
+        if (res) { F8 q = load8(res + r * ldr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] += q.v[e]; }
+        store8(y + r * ldy + c, o);
+    }
+}
+
+extern "C" int ss_bn_apply(int dtype, const void* z, int64_t ldz, const float* stats, const float* gamma, const float* beta,
+                           const void* res, int64_t ldr, const float* mask, int64_t rows_per_image, void* y, int64_t ldy,
+                           int64_t rows, int C, int act, hipStream_t stream) {
+    SS_CHECK(z && stats && gamma && beta && y && rows > 0 && C > 0 && C % 8 == 0, "ss_bn_apply: bad arguments (C=%d)", C);
+    SS_CHECK(ldz >= C && ldy >= C && ldz % 8 == 0 && ldy % 8 == 0 && (!res || (ldr >= C && ldr % 8 == 0)), "ss_bn_apply: bad leading dimensions");
+    SS_CHECK(!mask || rows_per_image > 0, "ss_bn_apply: rows_per_image required with a mask");
+    int64_t total = rows * (C / 8);
+    int blocks = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)z, ldz, stats, gamma, beta,
+                                          (const T*)res, ldr, mask, rows_per_image, (T*)y, ldy, rows, C, act));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward, pass 1: g = dy * mask * act'(u);  partial sums of g and g * xhat
+template <typename T> struct BnBwdF {
+    static constexpr int K = 2;
+    const T* dy; int64_t ldd; const T* z; int64_t ldz; const float* stats; const float* gamma; const float* beta;
+    const float* mask; int64_t rows_per_image; int C; int act;
+    __device__ void operator()(int64_t row, int c0, float (&acc)[2][8]) const {
+        F8 d = load8(dy + row * ldd + c0), v = load8(z + row * ldz + c0), mu = load8(stats + c0), rs = load8(stats + C + c0);
+        F8 g = load8(gamma + c0), b = load8(beta + c0), m;
+        if (mask) m = load8(mask + (row / rows_per_image) * C + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float xh = (v.v[e] - mu.v[e]) * rs.v[e];
+            float gg = d.v[e];
+            if (mask) gg *= m.v[e];
+            if (act == 1) gg *= mish_grad(xh * g.v[e] + b.v[e]);
+            acc[0][e] += gg; acc[1][e] += gg * xh;
+        }
+    }
+};
+
+// dgb[0][c] = dgamma = sum g*xhat ; dgb[1][c] = dbeta = sum g ; coef[0][c] = mean g, coef[1][c] = mean g*xhat (0 in eval mode)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int C, int64_t n, int training,
+                                       float* __restrict__ dgb, float* __restrict__ coef) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nb; ++b) { s += partial[((int64_t)b * 2 + 0) * C + c]; q += partial[((int64_t)b * 2 + 1) * C + c]; }
+    dgb[c] = (float)q; dgb[C + c] = (float)s;
+    coef[c] = training ? (float)(s / (double)n) : 0.f;
+    coef[C + c] = training ? (float)(q / (double)n) : 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const T* __restrict__ dy, int64_t ldd, const T* __restrict__ z, int64_t ldz,
+        const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
+        int64_t rows_per_image, const float* __restrict__ coef, T* __restrict__ dz, int64_t ldo, int64_t rows, int C, int act) {
+    const int chunks = C / 8;
+    const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks; const int c = (int)(i % chunks) * 8;
+        F8 d = load8(dy + r * ldd + c), v = load8(z + r * ldz + c), mu = load8(stats + c), rs = load8(stats + C + c);
+        F8 g = load8(gamma + c), b = load8(beta + c), c1 = load8(coef + c), c2 = load8(coef + C + c), m, o;
+        if (mask) m = load8(mask + (r / rows_per_image) * C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float xh = (v.v[e] - mu.v[e]) * rs.v[e];
+            float gg = d.v[e];
+            if (mask) gg *= m.v[e];
+            if (act == 1) gg *= mish_grad(xh * g.v[e] + b.v[e]);
+            o.v[e] = g.v[e] * rs.v[e] * (gg - c1.v[e] - xh * c2.v[e]);
+        }
+        store8(dz + r * ldo + c, o);
+    }
+}
+
+// workspace: nb*2*C floats (partials) followed by 2*C floats (coefficients)
+extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, int64_t ldz, const float* stats, const float* gamma,
+                         const float* beta, const float* mask, int64_t rows_per_image, int training, void* dz, int64_t ldo,
+                         float* dgamma_dbeta, int64_t rows, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(dy && z && stats && gamma && beta && dz && dgamma_dbeta && workspace && rows > 0 && C > 0 && C % 8 == 0, "ss_bn_bwd: bad arguments");
+    SS_CHECK(ldd >= C && ldz >= C && ldo >= C && ldd % 8 == 0 && ldz % 8 == 0 && ldo % 8 == 0, "ss_bn_bwd: bad leading dimensions");
+    SS_CHECK(!mask || rows_per_image > 0, "ss_bn_bwd: rows_per_image required with a mask");
+    ColGeom g = col_geom(rows, C);
+    SS_CHECK(ws_bytes >= ((int64_t)g.nb * 2 * C + 2 * C) * 4, "ss_bn_bwd: workspace too small");
+    float* coef = workspace + (int64_t)g.nb * 2 * C;
+    int64_t total = rows * (C / 8);
+    int blocks = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+    SS_DISPATCH(dtype, {
+        BnBwdF<T> f{(const T*)dy, ldd, (const T*)z, ldz, stats, gamma, beta, mask, rows_per_image, C, act};
+        hipLaunchKernelGGL((colreduce_partial_kernel<BnBwdF<T>>), dim3(g.nb, 1), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, workspace, g.nb, C, rows, training, dgamma_dbeta, coef);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL((bn_bwd_dz_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)dy, ldd, (const T*)z, ldz, stats, gamma, beta,
+                           mask, rows_per_image, coef, (T*)dz, ldo, rows, C, act);
+    });
+    SS_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,337 @@
+// Layout / resampling kernels on channels-last tensors: im2col + col2im for the overlapped PatchEmbed convolutions and
+// the non-overlapping spatial-reduction conv, bilinear resize forward/backward writing into channel
+// slices of concat buffers (K10), NCHW image -> NHWC, weight packing / casting, small elementwise helpers.
+// All bandwidth-bound: 16-byte channel-contiguous accesses wherever C % 8 == 0, scalar fall-backs for C = 3 / 6.
+#include "common.h"
+
+// ------------------------------------------------------------------ im2col / col2im   (column order: ky, kx, c)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_vec_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int H, int W, int C,
+                                                         int k, int s, int pad, int ho, int wo) {
+    const int chunks = C / 8, kk = k * k;
+    const int64_t total = (int64_t)B * ho * wo * kk * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks) * 8; int64_t p = i / chunks;
+        const int tap = (int)(p % kk); p /= kk;
+        const int ox = (int)(p % wo); int64_t q = p / wo; const int oy = (int)(q % ho); const int64_t b = q / ho;
+        const int iy = oy * s - pad + tap / k, ix = ox * s - pad + tap % k;
+        F8 v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? load8(x + ((b * H + iy) * W + ix) * C + c) : zero8();
+        store8(col + p * ((int64_t)kk * C) + (int64_t)tap * C + c, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_scalar_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int H, int W, int C,
+                                                            int k, int s, int pad, int ho, int wo, int Kp) {
+    const int64_t total = (int64_t)B * ho * wo * Kp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kc = (int)(i % Kp); int64_t p = i / Kp;
+        float v = 0.f;
+        if (kc < k * k * C) {
+            const int c = kc % C, tap = kc / C;
+            const int ox = (int)(p % wo); int64_t q = p / wo; const int oy = (int)(q % ho); const int64_t b = q / ho;
+            const int iy = oy * s - pad + tap / k, ix = ox * s - pad + tap % k;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = to_f(x[((b * H + iy) * W + ix) * C + c]);
+        }
+        col[i] = from_f<T>(v);
+    }
+}
+// gather form: every input pixel sums the taps that read it (deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ col, T* __restrict__ dx, int B, int H, int W, int C,
+                                                     int k, int s, int pad, int ho, int wo) {
+    const int chunks = C / 8, kk = k * k;
+    const int64_t total = (int64_t)B * H * W * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks) * 8; int64_t p = i / chunks;
+        const int ix = (int)(p % W); int64_t q = p / W; const int iy = (int)(q % H); const int64_t b = q / H;
+        F8 acc = zero8();
+        for (int ky = 0; ky < k; ++ky) {
+            int ty = iy + pad - ky;
+            if (ty < 0 || ty % s) continue;
+            int oy = ty / s; if (oy >= ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                int tx = ix + pad - kx;
+                if (tx < 0 || tx % s) continue;
+                int ox = tx / s; if (ox >= wo) continue;
+                F8 v = load8(col + ((b * ho + oy) * wo + ox) * ((int64_t)kk * C) + (int64_t)(ky * k + kx) * C + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc.v[e] += v.v[e];
+            }
+        }
+        store8(dx + p * C + c, acc);
+    }
+}
+
+extern "C" int ss_im2col(int dtype, const void* x, void* col, int B, int H, int W, int C, int k, int s, int pad, int Kp, hipStream_t stream) {
+    SS_CHECK(x && col && B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && s > 0 && pad >= 0, "ss_im2col: bad arguments");
+    const int ho = (H + 2 * pad - k) / s + 1, wo = (W + 2 * pad - k) / s + 1;
+    SS_CHECK(ho > 0 && wo > 0 && Kp >= k * k * C, "ss_im2col: bad geometry");
+    if (C % 8 == 0) {
+        SS_CHECK(Kp == k * k * C, "ss_im2col: Kp must equal k*k*C when C is a multiple of 8");
+        int64_t total = (int64_t)B * ho * wo * k * k * (C / 8);
+        int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((im2col_vec_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)x, (T*)col, B, H, W, C, k, s, pad, ho, wo));
+    } else {
+        int64_t total = (int64_t)B * ho * wo * Kp;
+        int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((im2col_scalar_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)x, (T*)col, B, H, W, C, k, s, pad, ho, wo, Kp));
+    }
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_col2im(int dtype, const void* col, void* dx, int B, int H, int W, int C, int k, int s, int pad, hipStream_t stream) {
+    SS_CHECK(col && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && k > 0 && s > 0 && pad >= 0, "ss_col2im: bad arguments (C=%d)", C);
+    const int ho = (H + 2 * pad - k) / s + 1, wo = (W + 2 * pad - k) / s + 1;
+    SS_CHECK(ho > 0 && wo > 0, "ss_col2im: bad geometry");
+    int64_t total = (int64_t)B * H * W * (C / 8);
+    int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((col2im_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)col, (T*)dx, B, H, W, C, k, s, pad, ho, wo));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ bilinear (align_corners = False), torch semantics
+struct LinTap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ LinTap lin_tap(int o, float scale, int in) {
+    float src = scale * (o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    LinTap t; t.i0 = (int)src; if (t.i0 > in - 1) t.i0 = in - 1;
+    t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
+    t.l1 = src - t.i0; t.l0 = 1.f - t.l1;
+    return t;
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+        int B, int hi, int wi, int ho, int wo, int C) {
+    constexpr int W8 = VEC ? 8 : 1;
+    const int chunks = C / W8;
+    const float sh = (float)hi / ho, sw = (float)wi / wo;
+    const int64_t total = (int64_t)B * ho * wo * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks) * W8; int64_t p = i / chunks;
+        const int ox = (int)(p % wo); int64_t q = p / wo; const int oy = (int)(q % ho); const int64_t b = q / ho;
+        const LinTap ty = lin_tap(oy, sh, hi), tx = lin_tap(ox, sw, wi);
+        const T* r0 = x + ((b * hi + ty.i0) * wi) * ldx + c;
+        const T* r1 = x + ((b * hi + ty.i1) * wi) * ldx + c;
+        if (VEC) {
+            F8 a = load8(r0 + tx.i0 * ldx), bq = load8(r0 + tx.i1 * ldx), cq = load8(r1 + tx.i0 * ldx), d = load8(r1 + tx.i1 * ldx), o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] = ty.l0 * (tx.l0 * a.v[e] + tx.l1 * bq.v[e]) + ty.l1 * (tx.l0 * cq.v[e] + tx.l1 * d.v[e]);
+            store8(y + p * ldy + c, o);
+        } else {
+            float o = ty.l0 * (tx.l0 * to_f(r0[tx.i0 * ldx]) + tx.l1 * to_f(r0[tx.i1 * ldx])) +
+                      ty.l1 * (tx.l0 * to_f(r1[tx.i0 * ldx]) + tx.l1 * to_f(r1[tx.i1 * ldx]));
+            y[p * ldy + c] = from_f<T>(o);
+        }
+    }
+}
+
+// gather-form backward: dx[b,iy,ix,:] = sum over the output pixels whose taps touch (iy,ix)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, int64_t ldy, T* __restrict__ dx, int64_t ldx,
+        int B, int hi, int wi, int ho, int wo, int C, int accumulate) {
+    constexpr int W8 = VEC ? 8 : 1;
+    const int chunks = C / W8;
+    const float sh = (float)hi / ho, sw = (float)wi / wo;
+    const int64_t total = (int64_t)B * hi * wi * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks) * W8; int64_t p = i / chunks;
+        const int ix = (int)(p % wi); int64_t q = p / wi; const int iy = (int)(q % hi); const int64_t b = q / hi;
+        int oy0 = (int)floorf((iy - 0.5f) / sh - 0.5f) - 1, oy1 = (int)ceilf((iy + 1.5f) / sh - 0.5f) + 1;
+        int ox0 = (int)floorf((ix - 0.5f) / sw - 0.5f) - 1, ox1 = (int)ceilf((ix + 1.5f) / sw - 0.5f) + 1;
+        oy0 = max(oy0, 0); ox0 = max(ox0, 0); oy1 = min(oy1, ho - 1); ox1 = min(ox1, wo - 1);
+        float acc[W8];
+#pragma unroll
+        for (int e = 0; e < W8; ++e) acc[e] = 0.f;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            const LinTap ty = lin_tap(oy, sh, hi);
+            const float wy = (ty.i0 == iy ? ty.l0 : 0.f) + (ty.i1 == iy ? ty.l1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                const LinTap tx = lin_tap(ox, sw, wi);
+                const float wx = (tx.i0 == ix ? tx.l0 : 0.f) + (tx.i1 == ix ? tx.l1 : 0.f);
+                if (wx == 0.f) continue;
+                const T* src = dy + ((b * ho + oy) * wo + ox) * ldy + c;
+                if (VEC) { F8 v = load8(src);
+#pragma unroll
+                    for (int e = 0; e < W8; ++e) acc[e] += wy * wx * v.v[e]; }
+                else acc[0] += wy * wx * to_f(src[0]);
+            }
+        }
+        T* dst = dx + p * ldx + c;
+        if (VEC) { F8 o;
+            if (accumulate) { o = load8(dst);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.v[e] += acc[e]; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.v[e] = acc[e]; }
+            store8(dst, o);
+        } else dst[0] = from_f<T>(accumulate ? to_f(dst[0]) + acc[0] : acc[0]);
+    }
+}
+
+extern "C" int ss_bilinear_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
+                               hipStream_t stream) {
+    SS_CHECK(x && y && B > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && C > 0 && ldx >= C && ldy >= C, "ss_bilinear_fwd: bad arguments");
+    const bool vec = C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y);
+    int64_t total = (int64_t)B * ho * wo * (vec ? C / 8 : C);
+    int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+    SS_DISPATCH(dtype, {
+        if (vec) hipLaunchKernelGGL((bilinear_fwd_kernel<T, true>), dim3(blocks), dim3(256), 0, stream, (const T*)x, ldx, (T*)y, ldy, B, hi, wi, ho, wo, C);
+        else hipLaunchKernelGGL((bilinear_fwd_kernel<T, false>), dim3(blocks), dim3(256), 0, stream, (const T*)x, ldx, (T*)y, ldy, B, hi, wi, ho, wo, C);
+    });
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_bilinear_bwd(int dtype, const void* dy, int64_t ldy, void* dx, int64_t ldx, int B, int hi, int wi, int ho, int wo, int C,
+                               int accumulate, hipStream_t stream) {
+    SS_CHECK(dy && dx && B > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && C > 0 && ldx >= C && ldy >= C, "ss_bilinear_bwd: bad arguments");
+    const bool vec = C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && aligned16(dx) && aligned16(dy);
+    int64_t total = (int64_t)B * hi * wi * (vec ? C / 8 : C);
+    int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+    SS_DISPATCH(dtype, {
+        if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true>), dim3(blocks), dim3(256), 0, stream, (const T*)dy, ldy, (T*)dx, ldx, B, hi, wi, ho, wo, C, accumulate);
+        else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false>), dim3(blocks), dim3(256), 0, stream, (const T*)dy, ldy, (T*)dx, ldx, B, hi, wi, ho, wo, C, accumulate);
+    });
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ casts, packing, small elementwise
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = from_f<TO>(to_f(src[i]));
+}
+// dst[c][r] = src[r][reverse ? Cc-1-c : c]     (small weight matrices; fp32 source)
+template <typename TO>
+__global__ void transpose_cast_kernel(const float* __restrict__ src, TO* __restrict__ dst, int R, int Cc, int reverse) {
+    const int64_t n = (int64_t)R * Cc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i / R), r = (int)(i % R);
+        dst[i] = from_f<TO>(src[(int64_t)r * Cc + (reverse ? Cc - 1 - c : c)]);
+    }
+}
+// conv weight [O][I][k][k] fp32 -> packed [O][Kp] (column order ky,kx,i; zero padded), optionally also transposed [Kp][O]
+template <typename TO>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, TO* __restrict__ wp, TO* __restrict__ wpt, int O, int I, int k, int Kp) {
+    const int64_t n = (int64_t)O * Kp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int o = (int)(i / Kp), kc = (int)(i % Kp);
+        float v = 0.f;
+        if (kc < k * k * I) { int ci = kc % I, tap = kc / I; v = w[(((int64_t)o * I + ci) * k + tap / k) * k + tap % k]; }
+        wp[i] = from_f<TO>(v);
+        if (wpt) wpt[(int64_t)kc * O + o] = from_f<TO>(v);
+    }
+}
+__global__ void unpack_conv_wgrad_kernel(const float* __restrict__ gp, float* __restrict__ g, int O, int I, int k, int Kp) {
+    const int64_t n = (int64_t)O * I * k * k;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int kx = (int)(i % k); int64_t t = i / k; int ky = (int)(t % k); t /= k; int ci = (int)(t % I); int o = (int)(t / I);
+        g[i] = gp[(int64_t)o * Kp + (ky * k + kx) * I + ci];
+    }
+}
+// image [B][C][H][W] fp32 -> [B][H][W][C] T
+template <typename TO>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, TO* __restrict__ y, int B, int C, int64_t HW) {
+    const int64_t n = (int64_t)B * C * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C); int64_t p = i / C; int64_t b = p / HW, hw = p % HW;
+        y[i] = from_f<TO>(x[(b * C + c) * HW + hw]);
+    }
+}
+// out = a + b  (8-wide)
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        F8 u = load8(a + i * 8), v = load8(b + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u.v[e] += v.v[e];
+        store8(out + i * 8, u);
+    }
+}
+// out[r][:] = x[r][:] * scale[r / rows_per_scale]
+template <typename T>
+__global__ void rowscale_kernel(const T* __restrict__ x, const float* __restrict__ scale, int64_t rows_per_scale, T* __restrict__ out,
+                                int64_t rows, int C) {
+    const int chunks = C / 8; const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float s = scale[(i / chunks) / rows_per_scale];
+        F8 v = load8(x + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.v[e] *= s;
+        store8(out + i * 8, v);
+    }
+}
+// y[b*rows + r][off .. off+C) = v[b][:]   (broadcast of the pooled branch into its concat slice)
+template <typename T>
+__global__ void bcast_rows_kernel(const T* __restrict__ v, T* __restrict__ y, int64_t ldy, int64_t rows_per_image, int64_t rows, int C) {
+    const int chunks = C / 8; const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks; const int c = (int)(i % chunks) * 8;
+        store8(y + r * ldy + c, load8(v + (r / rows_per_image) * C + c));
+    }
+}
+
+static inline int nblocks(int64_t n, int cap = 8192) { int64_t b = cdiv(n, 256); return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
+
+extern "C" int ss_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, hipStream_t stream) {
+    SS_CHECK(src && dst && n > 0, "ss_cast: bad arguments");
+    dim3 g(nblocks(n)), b(256);
+    if (src_dtype == SS_F32 && dst_dtype == SS_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), g, b, 0, stream, (const float*)src, (bf16*)dst, n);
+    else if (src_dtype == SS_BF16 && dst_dtype == SS_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), g, b, 0, stream, (const bf16*)src, (float*)dst, n);
+    else if (src_dtype == SS_F32 && dst_dtype == SS_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, stream, (const float*)src, (float*)dst, n);
+    else if (src_dtype == SS_BF16 && dst_dtype == SS_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), g, b, 0, stream, (const bf16*)src, (bf16*)dst, n);
+    else return ss_fail(-1, "ss_cast: unsupported dtypes %d -> %d", src_dtype, dst_dtype);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_transpose_cast(int dst_dtype, const float* src, void* dst, int R, int Cc, int reverse_cols, hipStream_t stream) {
+    SS_CHECK(src && dst && R > 0 && Cc > 0, "ss_transpose_cast: bad arguments");
+    dim3 g(nblocks((int64_t)R * Cc)), b(256);
+    SS_DISPATCH(dst_dtype, hipLaunchKernelGGL((transpose_cast_kernel<T>), g, b, 0, stream, src, (T*)dst, R, Cc, reverse_cols));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_pack_conv_weight(int dst_dtype, const float* w, void* wp, void* wpt, int O, int I, int k, int Kp, hipStream_t stream) {
+    SS_CHECK(w && wp && O > 0 && I > 0 && k > 0 && Kp >= k * k * I, "ss_pack_conv_weight: bad arguments");
+    dim3 g(nblocks((int64_t)O * Kp)), b(256);
+    SS_DISPATCH(dst_dtype, hipLaunchKernelGGL((pack_conv_weight_kernel<T>), g, b, 0, stream, w, (T*)wp, (T*)wpt, O, I, k, Kp));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_unpack_conv_wgrad(const float* gp, float* g, int O, int I, int k, int Kp, hipStream_t stream) {
+    SS_CHECK(gp && g && O > 0 && I > 0 && k > 0 && Kp >= k * k * I, "ss_unpack_conv_wgrad: bad arguments");
+    hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(nblocks((int64_t)O * I * k * k)), dim3(256), 0, stream, gp, g, O, I, k, Kp);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_nchw_to_nhwc(int dst_dtype, const float* x, void* y, int B, int C, int64_t HW, hipStream_t stream) {
+    SS_CHECK(x && y && B > 0 && C > 0 && HW > 0, "ss_nchw_to_nhwc: bad arguments");
+    dim3 g(nblocks((int64_t)B * C * HW, 16384)), b(256);
+    SS_DISPATCH(dst_dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), g, b, 0, stream, x, (T*)y, B, C, HW));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_add(int dtype, const void* a, const void* b, void* out, int64_t n, hipStream_t stream) {
+    SS_CHECK(a && b && out && n > 0 && n % 8 == 0, "ss_add: n must be a positive multiple of 8");
+    dim3 g(nblocks(n / 8, 16384)), bl(256);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((add_kernel<T>), g, bl, 0, stream, (const T*)a, (const T*)b, (T*)out, n / 8));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_rowscale(int dtype, const void* x, const float* scale, int64_t rows_per_scale, void* out, int64_t rows, int C, hipStream_t stream) {
+    SS_CHECK(x && scale && out && rows > 0 && C > 0 && C % 8 == 0 && rows_per_scale > 0, "ss_rowscale: bad arguments");
+    dim3 g(nblocks(rows * (C / 8), 16384)), b(256);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((rowscale_kernel<T>), g, b, 0, stream, (const T*)x, scale, rows_per_scale, (T*)out, rows, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_bcast_rows(int dtype, const void* v, void* y, int64_t ldy, int64_t rows_per_image, int64_t rows, int C, hipStream_t stream) {
+    SS_CHECK(v && y && rows > 0 && C > 0 && C % 8 == 0 && ldy >= C && ldy % 8 == 0 && rows_per_image > 0, "ss_bcast_rows: bad arguments");
+    dim3 g(nblocks(rows * (C / 8), 16384)), b(256);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((bcast_rows_kernel<T>), g, b, 0, stream, (const T*)v, (T*)y, ldy, rows_per_image, rows, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,426 @@
+"""Functional (non-autograd) wrappers over the C ABI of libsemseg_hip.so.
+
+Every function validates shapes / dtypes / contiguity on the host, borrows the tensors' device pointers for one
+asynchronous launch on the current torch HIP stream and returns torch tensors.  PyTorch is used for allocation only.
+There is no fallback: tensors must live on a HIP device and the library must be built.
+"""
+import torch
+from ._lib import lib, check
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_WS = {}
+COLRED_BLOCKS = 2048
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f'semseg_amd: unsupported dtype {t.dtype}')
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise RuntimeError('semseg_amd: tensors must live on a HIP device (no CPU fallback)')
+    return t.device
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def workspace(device, nbytes):
+    t = _WS.get(device)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 64 << 20), dtype=torch.uint8, device=device)
+        _WS[device] = t
+    return t
+
+
+def _mat(t, name):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f'{name}: expected a 2-D tensor with unit inner stride, got {tuple(t.shape)} / {t.stride()}')
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def _f32(t, name, n=None):
+    if t is None:
+        return
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f'{name}: expected contiguous float32')
+    if n is not None and t.numel() != n:
+        raise ValueError(f'{name}: expected {n} elements, got {t.numel()}')
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm_nt(a, b, out=None, bias=None, res=None, rowscale=None, rows_per_scale=0, act=0, out_f32=False):
+    """out[M,N] = (a[M,K] @ b[N,K]^T + bias) * rowscale[row // rows_per_scale] + res."""
+    dev = _dev(a)
+    M, K, lda = _mat(a, 'a')
+    N, Kb, ldb = _mat(b, 'b')
+    if K != Kb or a.dtype != b.dtype:
+        raise ValueError(f'gemm_nt: a {tuple(a.shape)} {a.dtype} vs b {tuple(b.shape)} {b.dtype}')
+    odt = torch.float32 if out_f32 else a.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=dev)
+    Mo, No, ldc = _mat(out, 'out')
+    if (Mo, No) != (M, N) or out.dtype != odt:
+        raise ValueError('gemm_nt: bad out')
+    ldr = 0
+    if res is not None:
+        Mr, Nr, ldr = _mat(res, 'res')
+        if (Mr, Nr) != (M, N) or res.dtype != odt:
+            raise ValueError('gemm_nt: bad res')
+    _f32(bias, 'bias', N)
+    if rowscale is not None:
+        _f32(rowscale, 'rowscale')
+        if rows_per_scale <= 0 or rowscale.numel() * rows_per_scale < M:
+            raise ValueError('gemm_nt: bad rowscale')
+    check(lib().ss_gemm_nt(dt(a), int(out_f32), _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, K, _p(bias), _p(res), ldr,
+                           _p(rowscale), rows_per_scale, act, _stream()))
+    return out
+
+
+def gemm_tn(a, b, out=None, accumulate=False):
+    """out[M,N] (fp32) (+)= a[R,M]^T @ b[R,N]."""
+    dev = _dev(a)
+    R, M, lda = _mat(a, 'a')
+    Rb, N, ldb = _mat(b, 'b')
+    if R != Rb or a.dtype != b.dtype:
+        raise ValueError(f'gemm_tn: a {tuple(a.shape)} vs b {tuple(b.shape)}')
+    if out is None:
+        if accumulate:
+            raise ValueError('gemm_tn: accumulate needs out')
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    Mo, No, ldc = _mat(out, 'out')
+    if (Mo, No) != (M, N) or out.dtype != torch.float32:
+        raise ValueError('gemm_tn: bad out')
+    nbytes = lib().ss_gemm_tn_workspace(dt(a), M, N, R)
+    ws = workspace(dev, nbytes)
+    check(lib().ss_gemm_tn(dt(a), _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, R, _p(ws), ws.numel(), int(accumulate), _stream()))
+    return out
+
+
+# ------------------------------------------------------------------ norms / reductions
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    if ld != C:
+        raise ValueError('layernorm_fwd: x must be dense')
+    _f32(gamma, 'gamma', C), _f32(beta, 'beta', C)
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=dev)
+    rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+    check(lib().ss_layernorm_fwd(dt(x), _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, C, eps, _stream()))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma):
+    """-> dx, dgb [2,C] fp32 (dgamma, dbeta)."""
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    if ld != C or dy.shape != x.shape or not dy.is_contiguous() or dy.dtype != x.dtype:
+        raise ValueError('layernorm_bwd: x/dy must be dense and alike')
+    _f32(gamma, 'gamma', C), _f32(mean, 'mean', rows), _f32(rstd, 'rstd', rows)
+    dx = torch.empty_like(x)
+    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, 1024 * 2 * C * 4)
+    check(lib().ss_layernorm_bwd(dt(x), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgb), dgb.data_ptr() + C * 4,
+                                 rows, C, _p(ws), ws.numel(), _stream()))
+    return dx, dgb
+
+
+def colsum(x, groups=1, scale=1.0, out=None, accumulate=False):
+    """out[g, c] (+)= scale * sum over the g-th block of rows of x[:, c]  (fp32)."""
+    dev = _dev(x)
+    rows_total, C, ld = _mat(x, 'x')
+    if rows_total % groups:
+        raise ValueError('colsum: rows not divisible by groups')
+    if out is None:
+        out = torch.empty((groups, C), dtype=torch.float32, device=dev)
+    _f32(out, 'out', groups * C)
+    ws = workspace(dev, groups * COLRED_BLOCKS * C * 4)
+    check(lib().ss_colsum(dt(x), _p(x), ld, rows_total // groups, C, groups, scale, _p(out), int(accumulate), _p(ws), ws.numel(), _stream()))
+    return out
+
+
+def bn_stats(x, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt=None):
+    """Batch statistics of x[rows, C] -> stats [2,C] (mean, rstd); updates the running buffers in place."""
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    _f32(running_mean, 'running_mean', C), _f32(running_var, 'running_var', C)
+    if nbt is not None and nbt.dtype != torch.int64:
+        raise ValueError('bn_stats: num_batches_tracked must be int64')
+    stats = torch.empty((2, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, COLRED_BLOCKS * 2 * C * 4)
+    check(lib().ss_bn_stats(dt(x), _p(x), ld, rows, C, eps, momentum, _p(stats), _p(running_mean), _p(running_var), _p(nbt),
+                            _p(ws), ws.numel(), _stream()))
+    return stats
+
+
+def bn_eval_stats(running_mean, running_var, eps=1e-5):
+    C = running_mean.numel()
+    _dev(running_mean)
+    _f32(running_mean, 'running_mean', C), _f32(running_var, 'running_var', C)
+    stats = torch.empty((2, C), dtype=torch.float32, device=running_mean.device)
+    check(lib().ss_bn_eval_stats(_p(running_mean), _p(running_var), C, eps, _p(stats), _stream()))
+    return stats
+
+
+def bn_apply(z, stats, gamma, beta, act=0, res=None, mask=None, rows_per_image=0, out=None):
+    dev = _dev(z)
+    rows, C, ldz = _mat(z, 'z')
+    _f32(stats, 'stats', 2 * C), _f32(gamma, 'gamma', C), _f32(beta, 'beta', C)
+    if out is None:
+        out = torch.empty((rows, C), dtype=z.dtype, device=dev)
+    ro, Co, ldy = _mat(out, 'out')
+    if (ro, Co) != (rows, C) or out.dtype != z.dtype:
+        raise ValueError('bn_apply: bad out')
+    ldr = 0
+    if res is not None:
+        rr, Cr, ldr = _mat(res, 'res')
+        if (rr, Cr) != (rows, C) or res.dtype != z.dtype:
+            raise ValueError('bn_apply: bad res')
+    if mask is not None:
+        _f32(mask, 'mask')
+        if rows_per_image <= 0 or mask.numel() * rows_per_image != rows * C:
+            raise ValueError('bn_apply: bad mask')
+    check(lib().ss_bn_apply(dt(z), _p(z), ldz, _p(stats), _p(gamma), _p(beta), _p(res), ldr, _p(mask), rows_per_image, _p(out), ldy,
+                            rows, C, act, _stream()))
+    return out
+
+
+def bn_bwd(dy, z, stats, gamma, beta, act=0, mask=None, rows_per_image=0, training=True, out=None):
+    """-> dz, dgb [2,C] fp32 (dgamma, dbeta)."""
+    dev = _dev(z)
+    rows, C, ldz = _mat(z, 'z')
+    rd, Cd, ldd = _mat(dy, 'dy')
+    if (rd, Cd) != (rows, C) or dy.dtype != z.dtype:
+        raise ValueError('bn_bwd: dy/z mismatch')
+    _f32(stats, 'stats', 2 * C), _f32(gamma, 'gamma', C), _f32(beta, 'beta', C)
+    if mask is not None:
+        _f32(mask, 'mask')
+        if rows_per_image <= 0 or mask.numel() * rows_per_image != rows * C:
+            raise ValueError('bn_bwd: bad mask')
+    if out is None:
+        out = torch.empty((rows, C), dtype=z.dtype, device=dev)
+    ro, Co, ldo = _mat(out, 'out')
+    if (ro, Co) != (rows, C) or out.dtype != z.dtype:
+        raise ValueError('bn_bwd: bad out')
+    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, (COLRED_BLOCKS * 2 * C + 2 * C) * 4)
+    check(lib().ss_bn_bwd(dt(z), _p(dy), ldd, _p(z), ldz, _p(stats), _p(gamma), _p(beta), _p(mask), rows_per_image, int(training),
+                          _p(out), ldo, _p(dgb), rows, C, act, _p(ws), ws.numel(), _stream()))
+    return out, dgb
+
+
+# ------------------------------------------------------------------ depthwise conv
+def dwconv3_fwd(x, w9c, bias, B, H, W, act=0):
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    if ld != C or rows != B * H * W:
+        raise ValueError('dwconv3_fwd: x must be dense [B*H*W, C]')
+    _f32(w9c, 'w9c', 9 * C), _f32(bias, 'bias', C)
+    y = torch.empty_like(x)
+    check(lib().ss_dwconv3_fwd(dt(x), _p(x), _p(w9c), _p(bias), _p(y), B, H, W, C, act, _stream()))
+    return y
+
+
+def dwconv3_bwd(dy, x, w9c, bias, B, H, W, act=0):
+    """-> g = dy * act'(dw(x)+b) [rows, C], dw_db [10, C] fp32 (9 taps tap-major, then bias)."""
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    if ld != C or rows != B * H * W or dy.shape != x.shape or not dy.is_contiguous() or dy.dtype != x.dtype:
+        raise ValueError('dwconv3_bwd: bad x / dy')
+    _f32(w9c, 'w9c', 9 * C), _f32(bias, 'bias', C)
+    g = torch.empty_like(x)
+    dwdb = torch.empty((10, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, COLRED_BLOCKS * 10 * C * 4)
+    check(lib().ss_dwconv3_bwd(dt(x), _p(dy), _p(x), _p(w9c), _p(bias), _p(g), _p(dwdb), B, H, W, C, act, _p(ws), ws.numel(), _stream()))
+    return g, dwdb
+
+
+# ------------------------------------------------------------------ MiT attention
+def mit_attn_fwd(q, kv, B, N, Nk, heads):
+    """q [B*N, C], kv [B*Nk, 2C] -> o [B*N, C], lse [B, heads, round32(N)]."""
+    dev = _dev(q)
+    rows, C, ld = _mat(q, 'q')
+    rk, C2, ldk = _mat(kv, 'kv')
+    D = C // heads
+    if ld != C or ldk != C2 or rows != B * N or rk != B * Nk or C2 != 2 * C or kv.dtype != q.dtype or D * heads != C:
+        raise ValueError(f'mit_attn_fwd: bad shapes q {tuple(q.shape)} kv {tuple(kv.shape)}')
+    o = torch.empty_like(q)
+    lse = torch.empty((B, heads, (N + 31) // 32 * 32), dtype=torch.float32, device=dev)
+    nbytes = lib().ss_mit_attn_fwd_workspace(dt(q), B, Nk, heads, D)
+    ws = workspace(dev, nbytes)
+    check(lib().ss_mit_attn_fwd(dt(q), _p(q), _p(kv), _p(o), _p(lse), B, N, Nk, heads, D, float(D) ** -0.5, _p(ws), ws.numel(), _stream()))
+    return o, lse
+
+
+def mit_attn_bwd(q, kv, o, dout, lse, B, N, Nk, heads):
+    dev = _dev(q)
+    rows, C, ld = _mat(q, 'q')
+    D = C // heads
+    for t, nm in ((o, 'o'), (dout, 'dout')):
+        if t.shape != q.shape or t.dtype != q.dtype or not t.is_contiguous():
+            raise ValueError(f'mit_attn_bwd: bad {nm}')
+    if not q.is_contiguous() or not kv.is_contiguous() or kv.shape != (B * Nk, 2 * C) or rows != B * N:
+        raise ValueError('mit_attn_bwd: bad q / kv')
+    _f32(lse, 'lse', B * heads * ((N + 31) // 32 * 32))
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    nbytes = lib().ss_mit_attn_bwd_workspace(dt(q), B, N, Nk, heads, D)
+    ws = workspace(dev, nbytes)
+    check(lib().ss_mit_attn_bwd(dt(q), _p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(dq), _p(dkv), B, N, Nk, heads, D, float(D) ** -0.5,
+                                _p(ws), ws.numel(), _stream()))
+    return dq, dkv
+
+
+# ------------------------------------------------------------------ im2col / col2im / bilinear
+def conv_out_size(n, k, s, pad):
+    return (n + 2 * pad - k) // s + 1
+
+
+def im2col(x, B, H, W, C, k, s, pad):
+    """x [B*H*W, C] -> col [B*ho*wo, Kp], Kp = round8(k*k*C); column order (ky, kx, c)."""
+    dev = _dev(x)
+    if not x.is_contiguous() or x.numel() != B * H * W * C:
+        raise ValueError('im2col: bad x')
+    ho, wo = conv_out_size(H, k, s, pad), conv_out_size(W, k, s, pad)
+    Kp = (k * k * C + 7) // 8 * 8
+    col = torch.empty((B * ho * wo, Kp), dtype=x.dtype, device=dev)
+    check(lib().ss_im2col(dt(x), _p(x), _p(col), B, H, W, C, k, s, pad, Kp, _stream()))
+    return col, ho, wo
+
+
+def col2im(col, B, H, W, C, k, s, pad):
+    dev = _dev(col)
+    ho, wo = conv_out_size(H, k, s, pad), conv_out_size(W, k, s, pad)
+    if not col.is_contiguous() or col.shape != (B * ho * wo, k * k * C):
+        raise ValueError('col2im: bad col')
+    dx = torch.empty((B * H * W, C), dtype=col.dtype, device=dev)
+    check(lib().ss_col2im(dt(col), _p(col), _p(dx), B, H, W, C, k, s, pad, _stream()))
+    return dx
+
+
+def bilinear_fwd(x, B, hi, wi, ho, wo, out=None):
+    """x [B*hi*wi, C] (row stride ld) -> out [B*ho*wo, C] (may be a channel slice of a wider buffer)."""
+    dev = _dev(x)
+    rows, C, ldx = _mat(x, 'x')
+    if rows != B * hi * wi:
+        raise ValueError('bilinear_fwd: bad x')
+    if out is None:
+        out = torch.empty((B * ho * wo, C), dtype=x.dtype, device=dev)
+    ro, Co, ldy = _mat(out, 'out')
+    if (ro, Co) != (B * ho * wo, C) or out.dtype != x.dtype:
+        raise ValueError('bilinear_fwd: bad out')
+    check(lib().ss_bilinear_fwd(dt(x), _p(x), ldx, _p(out), ldy, B, hi, wi, ho, wo, C, _stream()))
+    return out
+
+
+def bilinear_bwd(dy, B, hi, wi, ho, wo, out=None, accumulate=False):
+    """dy [B*ho*wo, C] -> dx [B*hi*wi, C]."""
+    dev = _dev(dy)
+    rows, C, ldy = _mat(dy, 'dy')
+    if rows != B * ho * wo:
+        raise ValueError('bilinear_bwd: bad dy')
+    if out is None:
+        if accumulate:
+            raise ValueError('bilinear_bwd: accumulate needs out')
+        out = torch.empty((B * hi * wi, C), dtype=dy.dtype, device=dev)
+    ro, Co, ldx = _mat(out, 'out')
+    if (ro, Co) != (B * hi * wi, C) or out.dtype != dy.dtype:
+        raise ValueError('bilinear_bwd: bad out')
+    check(lib().ss_bilinear_bwd(dt(dy), _p(dy), ldy, _p(out), ldx, B, hi, wi, ho, wo, C, int(accumulate), _stream()))
+    return out
+
+
+# ------------------------------------------------------------------ casts / packing / elementwise
+def cast(x, dtype):
+    _dev(x)
+    if not x.is_contiguous():
+        raise ValueError('cast: x must be contiguous')
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    if x.numel():
+        check(lib().ss_cast(dt(x), _DT[dtype], _p(x), _p(out), x.numel(), _stream()))
+    return out
+
+
+def transpose_cast(w, dtype, reverse_cols=False):
+    """fp32 w [R, Cc] -> [Cc, R] of dtype (optionally reading the columns in reverse order)."""
+    _dev(w)
+    R, Cc = w.shape
+    _f32(w, 'w')
+    out = torch.empty((Cc, R), dtype=dtype, device=w.device)
+    check(lib().ss_transpose_cast(_DT[dtype], _p(w), _p(out), R, Cc, int(reverse_cols), _stream()))
+    return out
+
+
+def pack_conv_weight(w, dtype, transposed=True):
+    """fp32 conv weight [O, I, k, k] -> packed [O, Kp] (ky,kx,i order, zero padded) and its transpose [Kp, O]."""
+    _dev(w)
+    O, I, k, k2 = w.shape
+    _f32(w, 'w')
+    Kp = (k * k * I + 7) // 8 * 8
+    wp = torch.empty((O, Kp), dtype=dtype, device=w.device)
+    wpt = torch.empty((Kp, O), dtype=dtype, device=w.device) if transposed else None
+    check(lib().ss_pack_conv_weight(_DT[dtype], _p(w), _p(wp), _p(wpt), O, I, k, Kp, _stream()))
+    return wp, wpt
+
+
+def unpack_conv_wgrad(gp, O, I, k):
+    _dev(gp)
+    Kp = (k * k * I + 7) // 8 * 8
+    _f32(gp, 'gp', O * Kp)
+    g = torch.empty((O, I, k, k), dtype=torch.float32, device=gp.device)
+    check(lib().ss_unpack_conv_wgrad(_p(gp), _p(g), O, I, k, Kp, _stream()))
+    return g
+
+
+def nchw_to_nhwc(x, dtype):
+    """fp32 image [B, C, H, W] -> [B*H*W, C] of dtype."""
+    _dev(x)
+    _f32(x, 'x')
+    B, C, H, W = x.shape
+    y = torch.empty((B * H * W, C), dtype=dtype, device=x.device)
+    check(lib().ss_nchw_to_nhwc(_DT[dtype], _p(x), _p(y), B, C, H * W, _stream()))
+    return y
+
+
+def add(a, b, out=None):
+    _dev(a)
+    if a.shape != b.shape or a.dtype != b.dtype or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError('add: operands must be alike and contiguous')
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().ss_add(dt(a), _p(a), _p(b), _p(out), a.numel(), _stream()))
+    return out
+
+
+def rowscale(x, scale, rows_per_scale):
+    _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    if ld != C:
+        raise ValueError('rowscale: x must be dense')
+    _f32(scale, 'scale')
+    if scale.numel() * rows_per_scale < rows:
+        raise ValueError('rowscale: scale too short')
+    out = torch.empty_like(x)
+    check(lib().ss_rowscale(dt(x), _p(x), _p(scale), rows_per_scale, _p(out), rows, C, _stream()))
+    return out
+
+
+def bcast_rows(v, out, rows_per_image):
+    """out[b*rows_per_image + r, :] = v[b, :]."""
+    _dev(v)
+    Bv, C, ldv = _mat(v, 'v')
+    rows, Co, ldy = _mat(out, 'out')
+    if ldv != C or Co != C or rows != Bv * rows_per_image or v.dtype != out.dtype:
+        raise ValueError('bcast_rows: bad shapes')
+    check(lib().ss_bcast_rows(dt(v), _p(v), _p(out), ldy, rows_per_image, rows, C, _stream()))
+    return out

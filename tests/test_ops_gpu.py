@@ -1,0 +1,238 @@
+"""GPU unit tests of the HIP kernels (through the C ABI) against plain fp32 PyTorch-CPU maths of the same op.
+Tolerances: fp32 1e-4 relative (north star), bf16 2e-2 relative to the tensor's max magnitude."""
+import math
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype):
+    return 1e-4 if dtype == torch.float32 else 2e-2
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-3))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def q(t, dtype):
+    """the fp32 values the kernel actually sees after storage rounding"""
+    return t.to(dtype).float().clone()
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from semseg_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N,K', [(300, 64, 64), (257, 320, 160), (128, 6, 512), (1000, 48, 32), (130, 512, 560), (64, 256, 6), (515, 136, 147)])
+def test_gemm_nt(ops, dtype, M, N, K):
+    a, b, bias, res = rnd(M, K), rnd(N, K, seed=1) / math.sqrt(K), rnd(N, seed=2), rnd(M, N, seed=3)
+    scale = torch.tensor([1.0, 0.0, 2.0, 0.5])
+    rps = (M + 3) // 4
+    ref = (q(a, dtype) @ q(b, dtype).t() + bias) * scale.repeat_interleave(rps)[:M, None] + q(res, dtype)
+    out = ops.gemm_nt(dev(a, dtype), dev(b, dtype), bias=dev(bias), res=dev(res, dtype), rowscale=dev(scale), rows_per_scale=rps)
+    assert out.dtype == dtype and rel(out, ref) < _tol(dtype)
+    out2 = ops.gemm_nt(dev(a, dtype), dev(b, dtype), act=1, out_f32=True)
+    assert out2.dtype == torch.float32 and rel(out2, F.gelu(q(a, dtype) @ q(b, dtype).t())) < (1e-4 if dtype == torch.float32 else 1e-3)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_gemm_nt_strided(ops, dtype):
+    big_a, b = rnd(200, 96), rnd(40, 32, seed=1)
+    a = dev(big_a, dtype)[:, 32:64]
+    outbuf = torch.zeros(200, 128, dtype=dtype, device='cuda')
+    ops.gemm_nt(a, dev(b, dtype), out=outbuf[:, 40:80])
+    ref = q(big_a[:, 32:64], dtype) @ q(b, dtype).t()
+    assert rel(outbuf[:, 40:80], ref) < _tol(dtype)
+    assert float(outbuf[:, :40].abs().max()) == 0 and float(outbuf[:, 80:].abs().max()) == 0
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('R,M,N', [(1000, 64, 64), (4097, 320, 160), (513, 6, 512), (300, 48, 32), (2048, 512, 136), (77, 8, 8)])
+def test_gemm_tn(ops, dtype, R, M, N):
+    a, b = rnd(R, M), rnd(R, N, seed=1)
+    ref = q(a, dtype).t() @ q(b, dtype)
+    out = ops.gemm_tn(dev(a, dtype), dev(b, dtype))
+    assert rel(out, ref) < (1e-4 if dtype == torch.float32 else 2e-3)
+    out2 = ops.gemm_tn(dev(a, dtype), dev(b, dtype), out=out.clone(), accumulate=True)
+    assert rel(out2, 2 * ref) < (1e-4 if dtype == torch.float32 else 2e-3)
+    # bit-exact reproducibility (fixed-order slab reduction, no atomics)
+    assert torch.equal(out, ops.gemm_tn(dev(a, dtype), dev(b, dtype)))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('rows,C', [(1000, 32), (777, 64), (300, 160), (129, 320), (64, 512), (50, 768)])
+def test_layernorm(ops, dtype, rows, C):
+    x, g, b, dy = rnd(rows, C, scale=2.0) + 0.5, 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2), rnd(rows, C, seed=3)
+    xr = q(x, dtype).requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    ref.backward(q(dy, dtype))
+    y, mean, rstd = ops.layernorm_fwd(dev(x, dtype), dev(g), dev(b), 1e-5)
+    assert rel(y, ref) < _tol(dtype)
+    dx, dgb = ops.layernorm_bwd(dev(dy, dtype), dev(x, dtype), mean, rstd, dev(g))
+    assert rel(dx, xr.grad) < _tol(dtype)
+    assert rel(dgb[0], gr.grad) < 1e-4 and rel(dgb[1], br.grad) < 1e-4
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('rows,C,act', [(2000, 64, 1), (333, 128, 0), (4, 256, 1), (70, 48, 1)])
+def test_batchnorm(ops, dtype, rows, C, act):
+    B = 2 if rows % 2 == 0 else 1
+    z, g, b, dy = rnd(rows, C, scale=1.5) + 0.3, 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2), rnd(rows, C, seed=3)
+    res = rnd(rows, C, seed=4)
+    mask = (torch.rand(B, C, generator=torch.Generator().manual_seed(1)) > 0.3).float() / 0.7
+    rm, rv = 0.1 * rnd(C, seed=5), 1 + 0.1 * rnd(C, seed=6).abs()
+    zr = q(z, dtype).requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    u = F.batch_norm(zr.t()[None], rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)[0].t()
+    ref = (F.mish(u) if act else u) * mask.repeat_interleave(rows // B, 0) + q(res, dtype)
+    ref.backward(q(dy, dtype))
+    rm_d, rv_d, nbt = dev(rm), dev(rv), torch.zeros((), dtype=torch.int64, device='cuda')
+    stats = ops.bn_stats(dev(z, dtype), 1e-5, 0.1, rm_d, rv_d, nbt)
+    assert rel(rm_d, rm_ref) < 1e-4 and rel(rv_d, rv_ref) < 1e-4 and int(nbt) == 1
+    y = ops.bn_apply(dev(z, dtype), stats, dev(g), dev(b), act, res=dev(res, dtype), mask=dev(mask), rows_per_image=rows // B)
+    assert rel(y, ref) < _tol(dtype)
+    dz, dgb = ops.bn_bwd(dev(dy, dtype), dev(z, dtype), stats, dev(g), dev(b), act, mask=dev(mask), rows_per_image=rows // B)
+    assert rel(dz, zr.grad) < _tol(dtype) * 2
+    assert rel(dgb[0], gr.grad) < 2e-4 and rel(dgb[1], br.grad) < 2e-4
+    # eval mode
+    zr2 = q(z, dtype).requires_grad_(True)
+    ref2 = F.batch_norm(zr2.t()[None], rm, rv, g, b, False, 0.1, 1e-5)[0].t()
+    ref2.backward(q(dy, dtype))
+    st2 = ops.bn_eval_stats(dev(rm), dev(rv))
+    assert rel(ops.bn_apply(dev(z, dtype), st2, dev(g), dev(b), 0), ref2) < _tol(dtype)
+    dz2, _ = ops.bn_bwd(dev(dy, dtype), dev(z, dtype), st2, dev(g), dev(b), 0, training=False)
+    assert rel(dz2, zr2.grad) < _tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_colsum(ops, dtype):
+    x = rnd(3 * 500, 64)
+    out = ops.colsum(dev(x, dtype), groups=3, scale=0.5)
+    assert rel(out, 0.5 * q(x, dtype).view(3, 500, 64).sum(1)) < 1e-4
+    wide = rnd(100, 96)
+    out = ops.colsum(dev(wide, dtype)[:, 32:64])
+    assert rel(out[0], q(wide, dtype)[:, 32:64].sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,H,W,C', [(2, 9, 7, 128), (1, 16, 16, 256), (2, 4, 4, 1024), (1, 5, 33, 8)])
+def test_dwconv3(ops, dtype, B, H, W, C):
+    x, w, b, dy = rnd(B, H, W, C), rnd(C, 1, 3, 3, seed=1) / 3, 0.1 * rnd(C, seed=2), rnd(B, H, W, C, seed=3)
+    xr = q(x, dtype).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.gelu(F.conv2d(xr, wr, br, padding=1, groups=C))
+    ref.backward(q(dy, dtype).permute(0, 3, 1, 2))
+    w9c = ops.transpose_cast(dev(w.view(C, 9)), torch.float32)
+    w9c_flip = ops.transpose_cast(dev(w.view(C, 9)), torch.float32, reverse_cols=True)
+    xd, dyd = dev(x, dtype).view(-1, C), dev(dy, dtype).view(-1, C)
+    y = ops.dwconv3_fwd(xd, w9c, dev(b), B, H, W, act=1)
+    assert rel(y.view(B, H, W, C), ref.permute(0, 2, 3, 1)) < _tol(dtype)
+    g, dwdb = ops.dwconv3_bwd(dyd, xd, w9c, dev(b), B, H, W, act=1)
+    dx = ops.dwconv3_fwd(g, w9c_flip, None, B, H, W, act=0)
+    assert rel(dx.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _tol(dtype) * 2
+    assert rel(dwdb[:9].t().reshape(C, 1, 3, 3), wr.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+    assert rel(dwdb[9], br.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,N,Nk,heads,D', [(2, 256, 4, 1, 32), (1, 1000, 100, 2, 64), (2, 64, 64, 5, 32), (1, 96, 256, 8, 64), (1, 33, 1, 1, 64)])
+def test_mit_attention(ops, dtype, B, N, Nk, heads, D):
+    C = heads * D
+    qq, kv, do = rnd(B * N, C), rnd(B * Nk, 2 * C, seed=1), rnd(B * N, C, seed=2)
+    qr, kvr = q(qq, dtype).requires_grad_(True), q(kv, dtype).requires_grad_(True)
+    qh = qr.view(B, N, heads, D).transpose(1, 2)
+    k, v = kvr.view(B, Nk, 2, heads, D).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(qh @ k.transpose(-2, -1) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, C)
+    ref.backward(q(do, dtype))
+    o, lse = ops.mit_attn_fwd(dev(qq, dtype), dev(kv, dtype), B, N, Nk, heads)
+    assert rel(o, ref) < _tol(dtype)
+    dq, dkv = ops.mit_attn_bwd(dev(qq, dtype), dev(kv, dtype), o, dev(do, dtype), lse, B, N, Nk, heads)
+    assert rel(dq, qr.grad) < _tol(dtype) * 2
+    assert rel(dkv, kvr.grad) < _tol(dtype) * 2
+
+
+def test_mit_attention_online_softmax_rescale(ops):
+    """a key far larger than the rest, placed in a late key tile, forces the running-max rescale branch"""
+    B, N, Nk, heads, D = 1, 64, 200, 1, 64
+    qq, kv = rnd(N, D), rnd(Nk, 2 * D, seed=1)
+    kv[150, :D] = 6.0 * qq[5]
+    qh, k, v = qq[None], kv[None, :, :D], kv[None, :, D:]
+    ref = (torch.softmax(qh @ k.transpose(-2, -1) * D ** -0.5, -1) @ v)[0]
+    o, _ = ops.mit_attn_fwd(dev(qq), dev(kv), B, N, Nk, heads)
+    assert rel(o, ref) < 1e-4
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('C,k,s,pad', [(3, 7, 4, 3), (32, 3, 2, 1), (64, 8, 8, 0), (16, 2, 2, 0)])
+def test_im2col_conv(ops, dtype, C, k, s, pad):
+    B, H, W, O = 2, 32, 24, 40
+    x, w = rnd(B, C, H, W), rnd(O, C, k, k, seed=1) / math.sqrt(C * k * k)
+    xr, wr = q(x, dtype).requires_grad_(True), q(w, dtype).requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=s, padding=pad)
+    dy = rnd(*ref.shape, seed=2)
+    ref.backward(q(dy, dtype))
+    xn = ops.nchw_to_nhwc(dev(x), dtype)
+    col, ho, wo = ops.im2col(xn, B, H, W, C, k, s, pad)
+    wp, wpt = ops.pack_conv_weight(dev(w), dtype)
+    y = ops.gemm_nt(col, wp)
+    assert rel(y.view(B, ho, wo, O), ref.permute(0, 2, 3, 1)) < _tol(dtype)
+    dyd = dev(dy.permute(0, 2, 3, 1).reshape(-1, O).contiguous(), dtype)
+    gw = ops.unpack_conv_wgrad(ops.gemm_tn(dyd, col), O, C, k)
+    assert rel(gw, wr.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+    if C % 8 == 0:
+        dcol = ops.gemm_nt(dyd, wpt)
+        dx = ops.col2im(dcol, B, H, W, C, k, s, pad)
+        assert rel(dx.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _tol(dtype) * 2
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('hi,wi,ho,wo,C', [(4, 4, 16, 16, 64), (8, 6, 16, 12, 16), (16, 16, 64, 64, 6), (5, 7, 13, 9, 8), (1, 1, 8, 8, 32)])
+def test_bilinear(ops, dtype, hi, wi, ho, wo, C):
+    B = 2
+    x = rnd(B, C, hi, wi)
+    xr = q(x, dtype).requires_grad_(True)
+    ref = F.interpolate(xr, size=(ho, wo), mode='bilinear', align_corners=False)
+    dy = rnd(*ref.shape, seed=1)
+    ref.backward(q(dy, dtype))
+    xd = dev(x.permute(0, 2, 3, 1).reshape(-1, C).contiguous(), dtype)
+    wide = torch.zeros(B * ho * wo, C + 16, dtype=dtype, device='cuda')
+    y = ops.bilinear_fwd(xd, B, hi, wi, ho, wo, out=wide[:, 8:8 + C])
+    assert rel(y.view(B, ho, wo, C), ref.permute(0, 2, 3, 1)) < _tol(dtype)
+    dyd = dev(dy.permute(0, 2, 3, 1).reshape(-1, C).contiguous(), dtype)
+    dx = ops.bilinear_bwd(dyd, B, hi, wi, ho, wo)
+    assert rel(dx.view(B, hi, wi, C), xr.grad.permute(0, 2, 3, 1)) < _tol(dtype)
+
+
+def test_small_helpers(ops):
+    x = rnd(64, 32)
+    xb = ops.cast(dev(x), torch.bfloat16)
+    assert torch.equal(xb.cpu(), x.to(torch.bfloat16))
+    assert torch.equal(ops.cast(xb, torch.float32).cpu(), x.to(torch.bfloat16).float())
+    assert torch.equal(ops.transpose_cast(dev(x), torch.float32).cpu(), x.t().contiguous())
+    assert torch.equal(ops.add(dev(x), dev(x)).cpu(), 2 * x)
+    s = torch.tensor([0.0, 2.0])
+    assert torch.equal(ops.rowscale(dev(x), dev(s), 32).cpu(), x * s.repeat_interleave(32)[:, None])
+    out = torch.zeros(2 * 10, 48, device='cuda')
+    ops.bcast_rows(dev(x[:2]), out[:, 8:40], 10)
+    assert torch.equal(out[:, 8:40].cpu(), x[:2].repeat_interleave(10, 0))
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.add(x, x)                      # CPU tensors are refused: no fallback path
