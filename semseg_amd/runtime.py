@@ -1,0 +1,49 @@
+"""Host-side runtime policy: compute dtype selection, layout adoption, DropPath multipliers."""
+import warnings
+import torch
+
+from . import ops
+
+_FORCED = None
+
+
+def set_compute_dtype(dtype):
+    """Force the activation dtype of every semseg_amd module (torch.float32 / torch.bfloat16), or None to follow
+    torch.autocast / the input dtype."""
+    global _FORCED
+    if dtype not in (None, torch.float32, torch.bfloat16):
+        raise ValueError('compute dtype must be float32, bfloat16 or None')
+    _FORCED = dtype
+
+
+def compute_dtype_for(x):
+    if _FORCED is not None:
+        return _FORCED
+    if torch.is_autocast_enabled():
+        adt = torch.get_autocast_gpu_dtype()
+        if adt == torch.float16:
+            warnings.warn('semseg_amd computes reduced precision in bfloat16 (fp32 accumulation); fp16 autocast is mapped to bf16')
+            return torch.bfloat16
+        return adt
+    return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+
+
+def as_tokens_nhwc(x, dtype):
+    """[B, C, H, W] (any strides) -> channels-last token matrix [B*H*W, C] in `dtype`; zero-copy when x already is the
+    permuted view of a channels-last map (what SegFormer stages hand to each other)."""
+    b, c, h, w = x.shape
+    nhwc = x.permute(0, 2, 3, 1)
+    if x.dtype == dtype and nhwc.is_contiguous():
+        return nhwc.reshape(b * h * w, c)
+    if x.dtype == torch.float32 and x.is_contiguous() and not x.requires_grad:
+        return ops.nchw_to_nhwc(x, dtype)
+    return nhwc.contiguous().to(dtype).reshape(b * h * w, c)     # rare layouts: torch copy keeps autograd intact
+
+
+def drop_path_keep(b, drop_prob, dtype, device):
+    """Per-sample DropPath multiplier floor(kp + U[0,1)) / kp drawn exactly like modules/helpers.py:20-24 (same torch RNG
+    call, shape and dtype), returned as fp32 [B] for the GEMM epilogue."""
+    kp = 1 - drop_prob
+    r = kp + torch.rand((b, 1, 1), dtype=dtype, device=device)
+    r.floor_()
+    return (r.float() / kp).reshape(b).contiguous()

@@ -166,7 +166,9 @@ def test_mit_attention(ops, dtype, B, N, Nk, heads, D):
     o, lse = ops.mit_attn_fwd(dev(qq, dtype), dev(kv, dtype), B, N, Nk, heads)
     assert rel(o, ref) < _tol(dtype)
     dq, dkv = ops.mit_attn_bwd(dev(qq, dtype), dev(kv, dtype), o, dev(do, dtype), lse, B, N, Nk, heads)
-    assert rel(dq, qr.grad) < _tol(dtype) * 2
+    # Nk == 1 makes dq analytically zero: compare against the gradient scale of the op instead of max|ref| = 0
+    scale_q = max(float(qr.grad.abs().max()), 0.05)
+    assert float((dq.float().cpu() - qr.grad).abs().max()) / scale_q < _tol(dtype) * 2
     assert rel(dkv, kvr.grad) < _tol(dtype) * 2
 
 
