@@ -55,6 +55,13 @@ int ss_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean
 int ss_colsum(int dtype, const void* x, int64_t ld, int64_t rows, int C, int groups, float scale, float* out,
               int accumulate, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
+/* narrow variant (any C <= 32): bias gradient of the nc-class classifier modules/lawin.py:137; workspace >= 512*C floats */
+int ss_colsum_small(int dtype, const void* x, int64_t ld, int64_t rows, int C, float* out, float* workspace, int64_t ws_bytes,
+                    hipStream_t stream);
+/* gradient fan-in of torch.cat slices (modules/lawin.py:210,221): out[r][c] = sum_k x[r][k*slice_stride + c] + bvec[r/rows_per_image][c] */
+int ss_sum_slices(int dtype, const void* x, int64_t ld, int nslices, int slice_stride, const float* bvec, int64_t rows_per_image,
+                  void* out, int64_t rows, int C, hipStream_t stream);
+
 /* ---- nn.BatchNorm2d (+ nn.Mish) of modules/lawin.py:54,101-105 on channels-last rows.
  * stats = [2,C] fp32 (mean, rstd).  ss_bn_stats also updates running_mean/var (unbiased) and num_batches_tracked like
  * torch (pass NULLs to skip).  ss_bn_apply: y = res + mask[row/rows_per_image, c] * act(gamma*(z-mean)*rstd + beta),
@@ -111,6 +118,56 @@ int ss_nchw_to_nhwc(int dst_dtype, const float* x, void* y, int B, int C, int64_
 int ss_add(int dtype, const void* a, const void* b, void* out, int64_t n, hipStream_t stream);
 int ss_rowscale(int dtype, const void* x, const float* scale, int64_t rows_per_scale, void* out, int64_t rows, int C, hipStream_t stream);
 int ss_bcast_rows(int dtype, const void* v, void* y, int64_t ldy, int64_t rows_per_image, int64_t rows, int C, hipStream_t stream);
+
+/* ---- Lawin large-window attention (modules/lawin.py:18-94,140-179).  feat: [B,H,W,C] channels-last (H,W multiples of 8).
+ * For ratio r in {8,4,2} the reference's F.unfold(8r x 8r, pad 4(r-1)) + PatchEmbed pooling (:27-35,153-168) is replaced by ONE
+ * pooled grid G_r [B,gh,gw,C], gh = (H/8-1)*(8/r)+8: window (i,j) = the 8x8 cells at (i*8/r, j*8/r) (bit-identical values).
+ * amax: uint8 [B,gh,gw,C] arg-max position inside each r x r cell for the max-pool backward. */
+int ss_lawin_pool_fwd(int dtype, const void* feat, int64_t ld, void* G, void* amax, int B, int H, int W, int C, int r,
+                      hipStream_t stream);
+/* d(feat) = base + sum over r of the avg and arg-max shares of dG_r (fp32 [B,gh,gw,C]) */
+int ss_lawin_pool_bwd(int dtype, const float* dG8, const float* dG4, const float* dG2, const void* amax8, const void* amax4,
+                      const void* amax2, const void* base, int64_t ldb, void* dfeat, int64_t ldo, int B, int H, int W, int C,
+                      hipStream_t stream);
+/* window-ordered d(ctx) [B*nh*nw*64, C] -> dG_r (gather form, deterministic) */
+int ss_lawin_gather_bwd(int dtype, const void* dctx, float* dG, int B, int H, int W, int C, int r, hipStream_t stream);
+/* LawinAttn.position_mixing (:44-46,62-69): out[w,p',c] = x[w,p',c] + sum_p Wm[head(c)][p'][p] x[w,p,c] + bm[head(c)][p'];
+ * x gathered from G (xwin NULL) or read window-ordered (G NULL); transpose != 0 applies Wm^T without bias (backward).
+ * Wm: [heads][64][64] fp32, bm: [heads][64] fp32; out: [windows*64, C]. */
+int ss_lawin_mix(int dtype, const void* G, const void* xwin, const float* Wm, const float* bm, void* out, int B, int H, int W,
+                 int C, int r, int heads, int transpose, hipStream_t stream);
+int64_t ss_lawin_mix_wgrad_workspace(int B, int H, int W, int heads);
+/* dWb: [heads][64][65] fp32 (64 weight columns, then the bias column) */
+int ss_lawin_mix_wgrad(int dtype, const void* G, const void* dwin, float* dWb, int B, int H, int W, int C, int r, int heads,
+                       float* workspace, int64_t ws_bytes, hipStream_t stream);
+/* per (window, head) softmax(theta phi^T / sqrt(d)) g (:72-91).  theta / y / dy / dtheta: image-ordered rows, `inter` channels;
+ * pg / dpg: window-ordered rows [windows*64, 2*inter] = (phi | g).  lse: [windows][heads][64] fp32.  d = inter/heads in {2..64}. */
+int ss_lawin_attn_fwd(int dtype, const void* theta, int64_t ldt, const void* pg, void* y, int64_t ldy, float* lse, int B, int H,
+                      int W, int inter, int heads, hipStream_t stream);
+int ss_lawin_attn_bwd(int dtype, const void* theta, int64_t ldt, const void* pg, const void* y, int64_t ldy, const void* dy,
+                      int64_t lddy, const float* lse, void* dtheta, int64_t lddt, void* dpg, int B, int H, int W, int inter,
+                      int heads, hipStream_t stream);
+
+/* ---- OhemCrossEntropyLoss.forward (loss/seg_loss.py:121-167), fully on device.  logits: [B,C,H,W] addressed by element strides
+ * (sn,sc,sh,sw); labels int64 [B,H,W].  thr_state: the module's stateful threshold (device float, updated in place, :143-144).
+ * prob [B*H*W] fp32 and the 256-byte ctl record are kept by the caller for the backward. */
+int64_t ss_ohem_ce_workspace(int64_t npix);
+int ss_ohem_ce_fwd(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,
+                   int B, int C, int H, int W, int64_t ignore_index, double min_kept, float* thr_state, float* prob,
+                   void* ctl_out, float* loss, void* workspace, int64_t ws_bytes, hipStream_t stream);
+int ss_ohem_ce_bwd(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,
+                   const float* prob, const void* ctl, const float* gout, void* dlogits, int64_t on, int64_t oc, int64_t oh,
+                   int64_t ow, int B, int C, int H, int W, int64_t ignore_index, hipStream_t stream);
+/* ---- DiceLoss / dice_loss (loss/seg_loss.py:15-55,82-99) and class_weights (helper/weights.py:18-27):
+ * sums[b][c] = {sum p*[y=c], sum p, #[y=c]}; backward dprobs = gout*(coef_all[b][c] + coef_hit[b][c]*[y=c]). */
+int ss_dice_sums(int dtype, const void* probs, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels, int B,
+                 int C, int H, int W, float* sums, float* workspace, int64_t ws_bytes, hipStream_t stream);
+int ss_dice_bwd(int dtype, const int64_t* labels, const float* coef_hit, const float* coef_all, const float* gout, void* dprobs,
+                int64_t on, int64_t oc, int64_t oh, int64_t ow, int B, int C, int H, int W, hipStream_t stream);
+/* ---- SegmentationMetrics.update (helper/metrics.py:90-95 + torchmetrics ConfusionMatrix): cm[target][argmax] += 1, int64, exact;
+ * first maximum wins ties. */
+int ss_confusion_update(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,
+                        int64_t* cm, int B, int C, int H, int W, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@
 #pragma once
 #include "common.h"
 
-#define SS_COLRED_MAX_BLOCKS 2048
+#define SS_COLRED_MAX_BLOCKS 1024
 
 struct ColGeom { int cpb, rpb, nb; };
 static inline ColGeom col_geom(int64_t rows, int C) {
@@ -55,13 +55,24 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(F f, int64_t row
     }
 }
 
-// out[g][col] = scale * sum_b partial[g][b][col]   (ncols = K*C)
-static __global__ void colreduce_final_kernel(const float* __restrict__ partial, int nb, int ncols, float scale, float* __restrict__ out, int accumulate) {
-    int col = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
-    if (col >= ncols) return;
-    const float* p = partial + (int64_t)g * nb * ncols + col;
+// out[g][col] = scale * sum_b partial[g][b][col]   (ncols = K*C).  32 columns x 8 row-parts per block, fixed summation order.
+static __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ partial, int nb, int ncols, float scale,
+                                                                   float* __restrict__ out, int accumulate) {
+    __shared__ float sh[8][33];
+    const int cx = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cx, g = blockIdx.y;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += p[(int64_t)b * ncols];
-    float* o = out + (int64_t)g * ncols + col;
-    *o = accumulate ? *o + scale * s : scale * s;
+    if (col < ncols) {
+        const float* p = partial + (int64_t)g * nb * ncols + col;
+        for (int b = part; b < nb; b += 8) s += p[(int64_t)b * ncols];
+    }
+    sh[part][cx] = s;
+    __syncthreads();
+    if (part == 0 && col < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k][cx];
+        float* o = out + (int64_t)g * ncols + col;
+        *o = accumulate ? *o + scale * t : scale * t;
+    }
 }

@@ -1,0 +1,451 @@
+// Lawin head: multi-scale large-window attention (reference modules/lawin.py:18-94,140-179).
+//
+// The reference materialises, per ratio r in {8,4,2}, an unfolded (8r x 8r) context patch per 8x8 window (64x/16x/4x
+// the feature map) and pools it.  Here the context of ALL windows is 8x8 gathers from ONE pooled grid per r:
+//   G_r[g] = 0.5*(max + avg) over feat rows [g*r - pad, g*r - pad + r),  pad = 4(r-1)  (zero padding participates),
+//   window (i,j) reads cells (i*8/r + py, j*8/r + px)  -- bit-identical values, 1/64..1/4 of the traffic.
+// Kernels (all deterministic, no atomics):
+//   lawin_pool_fwd      feat -> G_r (+ arg-max position per cell for the backward)
+//   lawin_mix           per-head position mixing  ctx' = ctx + Linear_{head}(ctx over the 64 positions)  (and its transpose)
+//   lawin_gather_bwd    window-ordered d(ctx) -> dG_r (gather form over the <= 64 windows sharing a cell)
+//   lawin_pool_bwd      dG_8, dG_4, dG_2 -> d(feat)  (avg share + arg-max share), one pass
+//   lawin_mix_wgrad     position-mixing weight / bias gradients
+//   lawin_attn_fwd/bwd  per (window, head) 64x64 softmax attention on the vector ALU (head dims 2..64 make MFMA tiles
+//                       mostly padding; the op is bandwidth / VALU bound), one wave per (window, head), lane = query
+//                       (and lane = key for the dphi/dg pass), phi/g/theta/dY rows broadcast from LDS.
+#include "common.h"
+#include "colreduce.h"
+
+struct WinGeom { int B, H, W, nh, nw, r, st, pad, gh, gw; };
+static inline WinGeom win_geom(int B, int H, int W, int r) {
+    WinGeom g; g.B = B; g.H = H; g.W = W; g.nh = H / 8; g.nw = W / 8; g.r = r; g.st = 8 / r; g.pad = 4 * (r - 1);
+    g.gh = (g.nh - 1) * g.st + 8; g.gw = (g.nw - 1) * g.st + 8;
+    return g;
+}
+
+// ------------------------------------------------------------------ pooled context grid
+template <typename T>
+__global__ __launch_bounds__(256) void lawin_pool_fwd_kernel(const T* __restrict__ feat, int64_t ld, T* __restrict__ G,
+                                                             unsigned char* __restrict__ amax, WinGeom g, int C) {
+    const int chunks = C / 8;
+    const int64_t total = (int64_t)g.B * g.gh * g.gw * chunks;
+    const float inv = 1.f / (g.r * g.r);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks) * 8; int64_t p = i / chunks;
+        const int gx = (int)(p % g.gw); int64_t q = p / g.gw; const int gy = (int)(q % g.gh); const int64_t b = q / g.gh;
+        const int y0 = gy * g.r - g.pad, x0 = gx * g.r - g.pad;
+        float mx[8], sm[8]; int am[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; sm[e] = 0.f; am[e] = 0; }
+        for (int dy = 0; dy < g.r; ++dy)
+            for (int dx = 0; dx < g.r; ++dx) {
+                const int y = y0 + dy, x = x0 + dx;
+                F8 v = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? load8(feat + ((b * g.H + y) * g.W + x) * ld + c) : zero8();
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sm[e] += v.v[e]; if (v.v[e] > mx[e]) { mx[e] = v.v[e]; am[e] = dy * g.r + dx; } }
+            }
+        F8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = 0.5f * (mx[e] + sm[e] * inv);
+        store8(G + p * C + c, o);
+        unsigned long long packed = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) packed |= (unsigned long long)(am[e] & 0xff) << (8 * e);
+        *(unsigned long long*)(amax + p * C + c) = packed;
+    }
+}
+
+// d(feat)[b,y,x,:] = base + sum_r ( 0.5/r^2 * dG_r[cell] + 0.5 * dG_r[cell] * [amax_r[cell] == position] )
+struct PoolBwdArgs { const float* dG[3]; const unsigned char* amax[3]; WinGeom g[3]; };
+template <typename T>
+__global__ __launch_bounds__(256) void lawin_pool_bwd_kernel(PoolBwdArgs a, const T* __restrict__ base, int64_t ldb, T* __restrict__ dfeat,
+                                                             int64_t ldo, int C) {
+    const int chunks = C / 8;
+    const WinGeom g0 = a.g[0];
+    const int64_t total = (int64_t)g0.B * g0.H * g0.W * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks) * 8; int64_t p = i / chunks;
+        const int x = (int)(p % g0.W); int64_t q = p / g0.W; const int y = (int)(q % g0.H); const int64_t b = q / g0.H;
+        F8 acc = base ? load8(base + p * ldb + c) : zero8();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const WinGeom g = a.g[k];
+            const int gy = (y + g.pad) / g.r, gx = (x + g.pad) / g.r;
+            const int idx = ((y + g.pad) % g.r) * g.r + (x + g.pad) % g.r;
+            const int64_t cell = ((b * g.gh + gy) * g.gw + gx) * C + c;
+            F8 d = load8(a.dG[k] + cell);
+            const unsigned long long am = *(const unsigned long long*)(a.amax[k] + cell);
+            const float w = 0.5f / (g.r * g.r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc.v[e] += d.v[e] * (w + ((int)((am >> (8 * e)) & 0xff) == idx ? 0.5f : 0.f));
+        }
+        store8(dfeat + p * ldo + c, acc);
+    }
+}
+
+// dG[b,gy,gx,:] = sum over the windows (i,j) whose 8x8 cell block contains (gy,gx) of dctx[(b,i,j), (gy-i*st, gx-j*st), :]
+template <typename T>
+__global__ __launch_bounds__(256) void lawin_gather_bwd_kernel(const T* __restrict__ dctx, float* __restrict__ dG, WinGeom g, int C) {
+    const int chunks = C / 8;
+    const int64_t total = (int64_t)g.B * g.gh * g.gw * chunks;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % chunks) * 8; int64_t p = t / chunks;
+        const int gx = (int)(p % g.gw); int64_t q = p / g.gw; const int gy = (int)(q % g.gh); const int64_t b = q / g.gh;
+        F8 acc = zero8();
+        const int ilo = max(0, (gy - 7 + g.st - 1) / g.st), ihi = min(g.nh - 1, gy / g.st);
+        const int jlo = max(0, (gx - 7 + g.st - 1) / g.st), jhi = min(g.nw - 1, gx / g.st);
+        for (int i = ilo; i <= ihi; ++i)
+            for (int j = jlo; j <= jhi; ++j) {
+                const int py = gy - i * g.st, px = gx - j * g.st;
+                F8 v = load8(dctx + ((((b * g.nh + i) * g.nw + j) * 64) + py * 8 + px) * C + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc.v[e] += v.v[e];
+            }
+        store8(dG + p * C + c, acc);
+    }
+}
+
+// ------------------------------------------------------------------ position mixing over the 64 window positions
+// out[w, p', c] = sum_p M[head(c)][p'][p] * x[w, p, c] + bias,  M = W + I  (transpose: M = W^T + I, no bias)
+// x[w, p, c] comes either from the pooled grid (gather) or from a window-ordered tensor.
+template <typename T>
+__global__ __launch_bounds__(256) void lawin_mix_kernel(const T* __restrict__ G, const T* __restrict__ xwin, const float* __restrict__ Wm,
+        const float* __restrict__ bm, T* __restrict__ out, WinGeom g, int C, int heads, int transpose) {
+    __shared__ __attribute__((aligned(16))) float Ws[64 * 64];
+    __shared__ float bs[64];
+    const int hd = blockIdx.y, cg = C / heads, wpb = 256 / cg, t = threadIdx.x;
+    for (int i = t; i < 4096; i += 256) {
+        int pr = i >> 6, pc = i & 63;
+        float v = transpose ? Wm[(int64_t)hd * 4096 + pc * 64 + pr] : Wm[(int64_t)hd * 4096 + i];
+        Ws[i] = v + (pr == pc ? 1.f : 0.f);
+    }
+    if (t < 64) bs[t] = (bm && !transpose) ? bm[hd * 64 + t] : 0.f;
+    __syncthreads();
+    const int wl = t / cg, cl = t % cg;
+    const int64_t wi = (int64_t)blockIdx.x * wpb + wl;
+    const int64_t nwin = (int64_t)g.B * g.nh * g.nw;
+    if (wl >= wpb || wi >= nwin) return;
+    const int c = hd * cg + cl;
+    float x[64];
+    if (xwin) {
+#pragma unroll
+        for (int p = 0; p < 64; ++p) x[p] = to_f(xwin[(wi * 64 + p) * C + c]);
+    } else {
+        const int j = (int)(wi % g.nw); int64_t q = wi / g.nw; const int i = (int)(q % g.nh); const int64_t b = q / g.nh;
+        const T* base = G + ((b * g.gh + i * g.st) * g.gw + j * g.st) * C + c;
+#pragma unroll
+        for (int p = 0; p < 64; ++p) x[p] = to_f(base[((int64_t)(p >> 3) * g.gw + (p & 7)) * C]);
+    }
+    for (int pr = 0; pr < 64; ++pr) {
+        float acc = bs[pr];
+        const floatx4* wrow = (const floatx4*)&Ws[pr * 64];
+#pragma unroll
+        for (int p4 = 0; p4 < 16; ++p4) {
+            floatx4 wv = wrow[p4];
+            acc += wv[0] * x[4 * p4] + wv[1] * x[4 * p4 + 1] + wv[2] * x[4 * p4 + 2] + wv[3] * x[4 * p4 + 3];
+        }
+        out[(wi * 64 + pr) * C + c] = from_f<T>(acc);
+    }
+}
+
+// partial[chunk][hd][p'][0..63] = sum_{w in chunk, c in head} d[w,p',c] * x[w,p,c] ;  [..][64] = sum d[w,p',c]
+template <typename T>
+__global__ __launch_bounds__(256) void lawin_mix_wgrad_kernel(const T* __restrict__ G, const T* __restrict__ dwin, float* __restrict__ partial,
+                                                              WinGeom g, int C, int heads, int win_per_chunk) {
+    extern __shared__ float shm[];            // At[cg][64] | Xt[cg][64]
+    const int hd = blockIdx.y, cg = C / heads, t = threadIdx.x;
+    float* At = shm; float* Xt = shm + cg * 64;
+    const int pr = t >> 2, pq = t & 3;
+    const int64_t nwin = (int64_t)g.B * g.nh * g.nw;
+    const int64_t w0 = (int64_t)blockIdx.x * win_per_chunk, w1 = min(nwin, w0 + win_per_chunk);
+    float acc[16], accb = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int64_t wi = w0; wi < w1; ++wi) {
+        const int j = (int)(wi % g.nw); int64_t q = wi / g.nw; const int i = (int)(q % g.nh); const int64_t b = q / g.nh;
+        const T* gbase = G + ((b * g.gh + i * g.st) * g.gw + j * g.st) * C + hd * cg;
+        __syncthreads();
+        for (int e = t; e < 64 * cg; e += 256) {
+            int p = e / cg, cl = e % cg;
+            At[cl * 64 + p] = to_f(dwin[(wi * 64 + p) * C + hd * cg + cl]);
+            Xt[cl * 64 + p] = to_f(gbase[((int64_t)(p >> 3) * g.gw + (p & 7)) * C + cl]);
+        }
+        __syncthreads();
+        for (int cl = 0; cl < cg; ++cl) {
+            const float a = At[cl * 64 + pr];
+            const floatx4* xr = (const floatx4*)&Xt[cl * 64 + pq * 16];
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) { floatx4 xv = xr[e4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e4 * 4 + e] += a * xv[e]; }
+            accb += a;
+        }
+    }
+    float* dst = partial + (((int64_t)blockIdx.x * heads + hd) * 64 + pr) * 65;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dst[pq * 16 + e] = acc[e];
+    if (pq == 0) dst[64] = accb;
+}
+
+// ------------------------------------------------------------------ window attention, one wave per (window, head)
+// theta / y / dy / dtheta: image layout rows (b*H + 8i+qy)*W + 8j+qx, `inter` channels (ld given);
+// pg / dpg: window layout rows w*64 + k, 2*inter channels (phi | g).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void lawin_attn_fwd_kernel(const T* __restrict__ theta, int64_t ldt, const T* __restrict__ pg,
+        T* __restrict__ y, int64_t ldy, float* __restrict__ lse, WinGeom g, int inter, int heads, float c2) {
+    extern __shared__ __attribute__((aligned(16))) float shm[];     // per wave: phi[64][D] | g[64][D]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hd = blockIdx.y * (blockDim.x >> 6) + wave;
+    if (hd >= heads) return;
+    const int64_t wi = blockIdx.x;
+    const int j = (int)(wi % g.nw); int64_t q = wi / g.nw; const int i = (int)(q % g.nh); const int64_t b = q / g.nh;
+    float* ph = shm + wave * (2 * 64 * D); float* gg = ph + 64 * D;
+    const T* prow = pg + (wi * 64 + lane) * (2 * (int64_t)inter) + hd * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { ph[lane * D + d] = to_f(prow[d]); gg[lane * D + d] = to_f(prow[inter + d]); }
+    const int64_t row = (b * g.H + 8 * i + (lane >> 3)) * g.W + 8 * j + (lane & 7);
+    float th[D], acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { th[d] = to_f(theta[row * ldt + hd * D + d]) * c2; acc[d] = 0.f; }
+    __builtin_amdgcn_wave_barrier();
+    float m = -INFINITY, l = 0.f;
+#pragma unroll 2
+    for (int k = 0; k < 64; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) s += th[d] * ph[k * D + d];
+        const float mn = fmaxf(m, s), alpha = exp2f(m - mn), p = exp2f(s - mn);
+        m = mn; l = l * alpha + p;
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = acc[d] * alpha + p * gg[k * D + d];
+    }
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < D; ++d) y[row * ldy + hd * D + d] = from_f<T>(acc[d] * inv);
+    lse[(wi * heads + hd) * 64 + lane] = m + log2f(l);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void lawin_attn_bwd_kernel(const T* __restrict__ theta, int64_t ldt, const T* __restrict__ pg,
+        const T* __restrict__ y, int64_t ldy, const T* __restrict__ dy, int64_t lddy, const float* __restrict__ lse,
+        T* __restrict__ dtheta, int64_t lddt, T* __restrict__ dpg, WinGeom g, int inter, int heads, float c2, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float shm[];     // per wave: phi | g | theta*c2 | dY  [64][D] each, lse[64], delta[64]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hd = blockIdx.y * (blockDim.x >> 6) + wave;
+    if (hd >= heads) return;
+    const int64_t wi = blockIdx.x;
+    const int j = (int)(wi % g.nw); int64_t q = wi / g.nw; const int i = (int)(q % g.nh); const int64_t b = q / g.nh;
+    float* ph = shm + wave * (4 * 64 * D + 128); float* gg = ph + 64 * D; float* ts = gg + 64 * D; float* ds_ = ts + 64 * D;
+    float* ls = ds_ + 64 * D; float* dl = ls + 64;
+    const T* prow = pg + (wi * 64 + lane) * (2 * (int64_t)inter) + hd * D;
+    const int64_t row = (b * g.H + 8 * i + (lane >> 3)) * g.W + 8 * j + (lane & 7);
+    float delta = 0.f;
+    const float mylse = lse[(wi * heads + hd) * 64 + lane];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        ph[lane * D + d] = to_f(prow[d]); gg[lane * D + d] = to_f(prow[inter + d]);
+        const float tq = to_f(theta[row * ldt + hd * D + d]) * c2, dq = to_f(dy[row * lddy + hd * D + d]);
+        ts[lane * D + d] = tq; ds_[lane * D + d] = dq;
+        delta += dq * to_f(y[row * ldy + hd * D + d]);
+    }
+    ls[lane] = mylse; dl[lane] = delta;
+    __builtin_amdgcn_wave_barrier();
+    {   // pass A, lane = query: dtheta_q = scale * sum_k p (dp - delta) phi_k
+        float th[D], dq[D], acc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { th[d] = ts[lane * D + d]; dq[d] = ds_[lane * D + d]; acc[d] = 0.f; }
+#pragma unroll 2
+        for (int k = 0; k < 64; ++k) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { s += th[d] * ph[k * D + d]; dp += dq[d] * gg[k * D + d]; }
+            const float w = exp2f(s - mylse) * (dp - delta);
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] += w * ph[k * D + d];
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) dtheta[row * lddt + hd * D + d] = from_f<T>(acc[d] * scale);
+    }
+    T* drow = dpg + (wi * 64 + lane) * (2 * (int64_t)inter) + hd * D;
+    {   // pass B1, lane = key: dg_k = sum_q p dY_q
+        float pk[D], acc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { pk[d] = ph[lane * D + d]; acc[d] = 0.f; }
+#pragma unroll 2
+        for (int qq = 0; qq < 64; ++qq) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s += pk[d] * ts[qq * D + d];
+            const float p = exp2f(s - ls[qq]);
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] += p * ds_[qq * D + d];
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) drow[inter + d] = from_f<T>(acc[d]);
+    }
+    {   // pass B2, lane = key: dphi_k = scale * sum_q p (dp - delta_q) theta_q      (ts holds theta*c2: undo c2 at the end)
+        float pk[D], gk[D], acc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { pk[d] = ph[lane * D + d]; gk[d] = gg[lane * D + d]; acc[d] = 0.f; }
+#pragma unroll 2
+        for (int qq = 0; qq < 64; ++qq) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { s += pk[d] * ts[qq * D + d]; dp += gk[d] * ds_[qq * D + d]; }
+            const float w = exp2f(s - ls[qq]) * (dp - dl[qq]);
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] += w * ts[qq * D + d];
+        }
+        const float f = scale / c2;
+#pragma unroll
+        for (int d = 0; d < D; ++d) drow[d] = from_f<T>(acc[d] * f);
+    }
+}
+
+// ------------------------------------------------------------------ host entry points
+static int check_geom(int B, int H, int W, int r, int C, const char* who) {
+    if (!(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && (r == 8 || r == 4 || r == 2) && C > 0 && C % 8 == 0))
+        return ss_fail(-1, "%s: need H,W multiples of 8, r in {8,4,2}, C multiple of 8 (B=%d H=%d W=%d r=%d C=%d)", who, B, H, W, r, C);
+    return 0;
+}
+static inline int nblk(int64_t n, int cap = 16384) { int64_t b = cdiv(n, 256); return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
+
+extern "C" int ss_lawin_pool_fwd(int dtype, const void* feat, int64_t ld, void* G, void* amax, int B, int H, int W, int C, int r,
+                                 hipStream_t stream) {
+    SS_CHECK(feat && G && amax && ld >= C && ld % 8 == 0, "ss_lawin_pool_fwd: bad arguments");
+    if (check_geom(B, H, W, r, C, "ss_lawin_pool_fwd")) return -1;
+    WinGeom g = win_geom(B, H, W, r);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((lawin_pool_fwd_kernel<T>), dim3(nblk((int64_t)B * g.gh * g.gw * (C / 8))), dim3(256), 0, stream,
+                                          (const T*)feat, ld, (T*)G, (unsigned char*)amax, g, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ss_lawin_pool_bwd(int dtype, const float* dG8, const float* dG4, const float* dG2, const void* amax8, const void* amax4,
+                                 const void* amax2, const void* base, int64_t ldb, void* dfeat, int64_t ldo, int B, int H, int W, int C,
+                                 hipStream_t stream) {
+    SS_CHECK(dG8 && dG4 && dG2 && amax8 && amax4 && amax2 && dfeat && ldo >= C && ldo % 8 == 0 && (!base || (ldb >= C && ldb % 8 == 0)),
+             "ss_lawin_pool_bwd: bad arguments");
+    if (check_geom(B, H, W, 8, C, "ss_lawin_pool_bwd")) return -1;
+    PoolBwdArgs a;
+    a.dG[0] = dG8; a.dG[1] = dG4; a.dG[2] = dG2;
+    a.amax[0] = (const unsigned char*)amax8; a.amax[1] = (const unsigned char*)amax4; a.amax[2] = (const unsigned char*)amax2;
+    a.g[0] = win_geom(B, H, W, 8); a.g[1] = win_geom(B, H, W, 4); a.g[2] = win_geom(B, H, W, 2);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((lawin_pool_bwd_kernel<T>), dim3(nblk((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, a,
+                                          (const T*)base, ldb, (T*)dfeat, ldo, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ss_lawin_gather_bwd(int dtype, const void* dctx, float* dG, int B, int H, int W, int C, int r, hipStream_t stream) {
+    SS_CHECK(dctx && dG, "ss_lawin_gather_bwd: null pointer");
+    if (check_geom(B, H, W, r, C, "ss_lawin_gather_bwd")) return -1;
+    WinGeom g = win_geom(B, H, W, r);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((lawin_gather_bwd_kernel<T>), dim3(nblk((int64_t)B * g.gh * g.gw * (C / 8))), dim3(256), 0, stream,
+                                          (const T*)dctx, dG, g, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// Wm: [heads][64][64] fp32, bm: [heads][64] fp32.  Exactly one of G (pooled grid, gather) / xwin (window-ordered) is given.
+extern "C" int ss_lawin_mix(int dtype, const void* G, const void* xwin, const float* Wm, const float* bm, void* out, int B, int H, int W,
+                            int C, int r, int heads, int transpose, hipStream_t stream) {
+    SS_CHECK((G != nullptr) != (xwin != nullptr) && Wm && out, "ss_lawin_mix: need exactly one of G / xwin, and Wm, out");
+    if (check_geom(B, H, W, r, C, "ss_lawin_mix")) return -1;
+    SS_CHECK(heads > 0 && C % heads == 0 && C / heads <= 256, "ss_lawin_mix: C/heads must be an integer <= 256");
+    WinGeom g = win_geom(B, H, W, r);
+    const int cg = C / heads, wpb = 256 / cg;
+    const int64_t nwin = (int64_t)B * g.nh * g.nw;
+    dim3 grid((unsigned)cdiv(nwin, wpb), heads);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((lawin_mix_kernel<T>), grid, dim3(256), 0, stream, (const T*)G, (const T*)xwin, Wm, bm, (T*)out, g, C,
+                                          heads, transpose));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// dWb: [heads][64][65] fp32 (64 weight columns + bias).  workspace >= nchunks*heads*64*65 floats.
+extern "C" int64_t ss_lawin_mix_wgrad_workspace(int B, int H, int W, int heads) {
+    int64_t nwin = (int64_t)B * (H / 8) * (W / 8);
+    int64_t chunks = cdiv(2048, heads); if (chunks > nwin) chunks = nwin; if (chunks < 1) chunks = 1;
+    int64_t wpc = cdiv(nwin, chunks); chunks = cdiv(nwin, wpc);
+    return chunks * heads * 64 * 65 * 4;
+}
+extern "C" int ss_lawin_mix_wgrad(int dtype, const void* G, const void* dwin, float* dWb, int B, int H, int W, int C, int r, int heads,
+                                  float* workspace, int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(G && dwin && dWb && workspace, "ss_lawin_mix_wgrad: null pointer");
+    if (check_geom(B, H, W, r, C, "ss_lawin_mix_wgrad")) return -1;
+    SS_CHECK(heads > 0 && C % heads == 0 && C / heads <= 256, "ss_lawin_mix_wgrad: C/heads must be an integer <= 256");
+    WinGeom g = win_geom(B, H, W, r);
+    const int64_t nwin = (int64_t)B * g.nh * g.nw;
+    int64_t chunks = cdiv(2048, heads); if (chunks > nwin) chunks = nwin; if (chunks < 1) chunks = 1;
+    const int64_t wpc = cdiv(nwin, chunks); chunks = cdiv(nwin, wpc);
+    SS_CHECK(ws_bytes >= chunks * heads * 64 * 65 * 4, "ss_lawin_mix_wgrad: workspace too small");
+    const int cg = C / heads;
+    size_t shm = (size_t)2 * cg * 64 * sizeof(float);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((lawin_mix_wgrad_kernel<T>), dim3((unsigned)chunks, heads), dim3(256), shm, stream, (const T*)G,
+                                          (const T*)dwin, workspace, g, C, heads, (int)wpc));
+    SS_LAUNCH_CHECK();
+    const int ncols = heads * 64 * 65;
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(ncols, 32), 1), dim3(256), 0, stream, workspace, (int)chunks, ncols, 1.f, dWb, 0);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int D>
+static int attn_fwd_launch(const T* theta, int64_t ldt, const T* pg, T* y, int64_t ldy, float* lse, WinGeom g, int inter, int heads,
+                           hipStream_t stream) {
+    const size_t per_wave = (size_t)2 * 64 * D * sizeof(float);
+    int waves = (int)(131072 / per_wave); if (waves > 4) waves = 4; if (waves > heads) waves = heads; if (waves < 1) waves = 1;
+    const float scale = 1.f / sqrtf((float)D);
+    dim3 grid((unsigned)((int64_t)g.B * g.nh * g.nw), (unsigned)cdiv(heads, waves));
+    if (waves * per_wave > 65536)
+        SS_HIP(hipFuncSetAttribute((const void*)lawin_attn_fwd_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(waves * per_wave)));
+    hipLaunchKernelGGL((lawin_attn_fwd_kernel<T, D>), grid, dim3(64 * waves), waves * per_wave, stream, theta, ldt, pg, y, ldy, lse, g, inter, heads,
+                       scale * 1.4426950408889634f);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T, int D>
+static int attn_bwd_launch(const T* theta, int64_t ldt, const T* pg, const T* y, int64_t ldy, const T* dy, int64_t lddy, const float* lse,
+                           T* dtheta, int64_t lddt, T* dpg, WinGeom g, int inter, int heads, hipStream_t stream) {
+    const size_t per_wave = (size_t)(4 * 64 * D + 128) * sizeof(float);
+    int waves = (int)(131072 / per_wave); if (waves > 4) waves = 4; if (waves > heads) waves = heads; if (waves < 1) waves = 1;
+    const float scale = 1.f / sqrtf((float)D);
+    dim3 grid((unsigned)((int64_t)g.B * g.nh * g.nw), (unsigned)cdiv(heads, waves));
+    if (waves * per_wave > 65536)
+        SS_HIP(hipFuncSetAttribute((const void*)lawin_attn_bwd_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(waves * per_wave)));
+    hipLaunchKernelGGL((lawin_attn_bwd_kernel<T, D>), grid, dim3(64 * waves), waves * per_wave, stream, theta, ldt, pg, y, ldy, dy, lddy, lse, dtheta,
+                       lddt, dpg, g, inter, heads, scale * 1.4426950408889634f, scale);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+#define SS_D_SWITCH(D, CALL) \
+    switch (D) { case 1: { constexpr int DD = 1; CALL; } break; case 2: { constexpr int DD = 2; CALL; } break; case 4: { constexpr int DD = 4; CALL; } break; \
+                 case 8: { constexpr int DD = 8; CALL; } break; case 16: { constexpr int DD = 16; CALL; } break; \
+                 case 32: { constexpr int DD = 32; CALL; } break; case 64: { constexpr int DD = 64; CALL; } break; \
+                 default: return ss_fail(-1, "lawin attention: unsupported head dim %d", D); }
+
+// lse: [windows][heads][64] fp32
+extern "C" int ss_lawin_attn_fwd(int dtype, const void* theta, int64_t ldt, const void* pg, void* y, int64_t ldy, float* lse, int B, int H,
+                                 int W, int inter, int heads, hipStream_t stream) {
+    SS_CHECK(theta && pg && y && lse && heads > 0 && inter % heads == 0 && ldt >= inter && ldy >= inter, "ss_lawin_attn_fwd: bad arguments");
+    if (check_geom(B, H, W, 8, 8, "ss_lawin_attn_fwd")) return -1;
+    WinGeom g = win_geom(B, H, W, 8);
+    const int D = inter / heads;
+    int rc = 0;
+    SS_DISPATCH(dtype, SS_D_SWITCH(D, rc = (attn_fwd_launch<T, DD>((const T*)theta, ldt, (const T*)pg, (T*)y, ldy, lse, g, inter, heads, stream))));
+    return rc;
+}
+extern "C" int ss_lawin_attn_bwd(int dtype, const void* theta, int64_t ldt, const void* pg, const void* y, int64_t ldy, const void* dy,
+                                 int64_t lddy, const float* lse, void* dtheta, int64_t lddt, void* dpg, int B, int H, int W, int inter,
+                                 int heads, hipStream_t stream) {
+    SS_CHECK(theta && pg && y && dy && lse && dtheta && dpg && heads > 0 && inter % heads == 0, "ss_lawin_attn_bwd: bad arguments");
+    SS_CHECK(ldt >= inter && ldy >= inter && lddy >= inter && lddt >= inter, "ss_lawin_attn_bwd: bad leading dimensions");
+    if (check_geom(B, H, W, 8, 8, "ss_lawin_attn_bwd")) return -1;
+    WinGeom g = win_geom(B, H, W, 8);
+    const int D = inter / heads;
+    int rc = 0;
+    SS_DISPATCH(dtype, SS_D_SWITCH(D, rc = (attn_bwd_launch<T, DD>((const T*)theta, ldt, (const T*)pg, (const T*)y, ldy, (const T*)dy, lddy, lse,
+                                                                   (T*)dtheta, lddt, (T*)dpg, g, inter, heads, stream))));
+    return rc;
+}

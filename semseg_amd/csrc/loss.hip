@@ -1,0 +1,353 @@
+// Per-pixel losses and the confusion-matrix accumulator (reference loss/seg_loss.py, helper/weights.py,
+// helper/metrics.py:90-95).  Logits/probabilities are addressed with explicit (n, c, h, w) element strides so both
+// NCHW-contiguous tensors and the channels-last views the networks return are read in place.  Labels: int64 [B,H,W].
+//
+// OHEM cross-entropy runs entirely on the device (no host sync): true-class probability + NLL per pixel, an exact radix
+// select (3 histogram passes over the float bit patterns) of the k-th smallest valid probability with the reference's
+// stable-order tie rule AND its quirk (the index found among the VALID pixels is applied to the ALL-pixel vector,
+// loss/seg_loss.py:141-143), the stateful never-decreasing threshold (:143-144), then a fixed-order masked mean.
+#include "common.h"
+
+struct Strides { int64_t n, c, h, w; };
+struct OhemCtl {
+    long long num_valid, k, krem, kept, j;
+    unsigned prefix; int do_select; int chunk; long long valid_before, eq_before;
+    float thr; float loss_sum;
+};
+#define OHEM_CHUNK 4096
+#define OHEM_BINS 2048
+
+template <typename T>
+__device__ __forceinline__ void softmax_stats(const T* __restrict__ p, int64_t sc, int C, float& mx, float& sum) {
+    mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, to_f(p[c * sc]));
+    sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += expf(to_f(p[c * sc]) - mx);
+}
+__device__ __forceinline__ int64_t pix_off(int64_t i, int H, int W, const Strides& s) {
+    const int x = (int)(i % W); const int64_t q = i / W; const int y = (int)(q % H); const int64_t b = q / H;
+    return b * s.n + y * s.h + x * s.w;
+}
+
+// prob[i] = softmax(logits)[label] (0 if the label is outside [0,C)), nll[i] = -log prob, vkey[i] = float bits of prob for valid
+// pixels (label != ignore) else 0xFFFFFFFF; ctl->num_valid += #valid
+template <typename T>
+__global__ __launch_bounds__(256) void ce_prob_kernel(const T* __restrict__ logits, Strides s, const long long* __restrict__ labels,
+        float* __restrict__ prob, float* __restrict__ nll, unsigned* __restrict__ vkey, OhemCtl* ctl, int64_t npix, int H, int W, int C,
+        long long ignore) {
+    long long nv = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const T* p = logits + pix_off(i, H, W, s);
+        const long long lab = labels[i];
+        float mx, sum; softmax_stats(p, s.c, C, mx, sum);
+        float pr = 0.f, nl = 0.f;
+        if (lab >= 0 && lab < C) { const float z = to_f(p[lab * s.c]) - mx; nl = logf(sum) - z; pr = expf(z) / sum; }
+        const bool valid = lab != ignore;
+        prob[i] = pr; nll[i] = nl; vkey[i] = valid ? __float_as_uint(pr) : 0xFFFFFFFFu;
+        nv += valid;
+    }
+    __shared__ long long sh[256];
+    sh[threadIdx.x] = nv; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0 && sh[0]) atomicAdd((unsigned long long*)&ctl->num_valid, (unsigned long long)sh[0]);
+}
+
+__global__ void ohem_plan_kernel(OhemCtl* ctl, double min_kept) {
+    const long long nv = ctl->num_valid;
+    const long long k = (long long)(min_kept * (double)nv);          // int(self.min_kept * valid_prob.numel())
+    ctl->k = k; ctl->krem = k; ctl->prefix = 0;
+    ctl->do_select = (k < nv && nv > 0 && k > 0) ? 1 : 0;
+}
+
+// pass 0: bits 31..21, pass 1: bits 20..10, pass 2: bits 9..0
+__device__ __forceinline__ void pass_bits(int pass, int& shift, unsigned& mask, unsigned& himask) {
+    if (pass == 0) { shift = 21; mask = 0x7FF; himask = 0; }
+    else if (pass == 1) { shift = 10; mask = 0x7FF; himask = 0xFFE00000u; }
+    else { shift = 0; mask = 0x3FF; himask = 0xFFFFFC00u; }
+}
+__global__ __launch_bounds__(256) void ohem_hist_kernel(const unsigned* __restrict__ vkey, int64_t npix, const OhemCtl* ctl,
+                                                        unsigned* __restrict__ hist, int pass) {
+    if (!ctl->do_select) return;
+    __shared__ unsigned sh[OHEM_BINS];
+    for (int i = threadIdx.x; i < OHEM_BINS; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    int shift; unsigned mask, himask; pass_bits(pass, shift, mask, himask);
+    const unsigned prefix = ctl->prefix;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned key = vkey[i];
+        if (key != 0xFFFFFFFFu && (key & himask) == prefix) atomicAdd(&sh[(key >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < OHEM_BINS; i += blockDim.x) if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+__global__ void ohem_scan_kernel(OhemCtl* ctl, const unsigned* __restrict__ hist, int pass) {
+    if (!ctl->do_select) return;
+    int shift; unsigned mask, himask; pass_bits(pass, shift, mask, himask);
+    long long rem = ctl->krem, cum = 0;
+    for (unsigned b = 0; b <= mask; ++b) {
+        const long long h = hist[b];
+        if (cum + h >= rem) { ctl->prefix |= b << shift; ctl->krem = rem - cum; return; }
+        cum += h;
+    }
+}
+// per chunk of OHEM_CHUNK pixels: number of valid pixels and of valid pixels whose key equals the selected value
+__global__ __launch_bounds__(256) void ohem_chunk_count_kernel(const unsigned* __restrict__ vkey, int64_t npix, const OhemCtl* ctl,
+                                                               unsigned* __restrict__ cnt_valid, unsigned* __restrict__ cnt_eq) {
+    if (!ctl->do_select) return;
+    const unsigned target = ctl->prefix;
+    const int64_t base = (int64_t)blockIdx.x * OHEM_CHUNK;
+    unsigned nv = 0, ne = 0;
+    for (int e = threadIdx.x; e < OHEM_CHUNK; e += 256) {
+        const int64_t i = base + e;
+        if (i < npix) { const unsigned key = vkey[i]; nv += key != 0xFFFFFFFFu; ne += key == target; }
+    }
+    __shared__ unsigned s1[256], s2[256];
+    s1[threadIdx.x] = nv; s2[threadIdx.x] = ne; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; } __syncthreads(); }
+    if (threadIdx.x == 0) { cnt_valid[blockIdx.x] = s1[0]; cnt_eq[blockIdx.x] = s2[0]; }
+}
+// one block: find the chunk holding the krem-th occurrence (in pixel order) of the selected value
+__global__ __launch_bounds__(1024) void ohem_locate_chunk_kernel(OhemCtl* ctl, const unsigned* __restrict__ cnt_valid,
+                                                                 const unsigned* __restrict__ cnt_eq, int nchunks) {
+    if (!ctl->do_select) return;
+    __shared__ long long sv[1024], se[1024];
+    const int t = threadIdx.x, per = (nchunks + 1023) / 1024;
+    long long v = 0, e = 0;
+    for (int c = t * per; c < min(nchunks, (t + 1) * per); ++c) { v += cnt_valid[c]; e += cnt_eq[c]; }
+    sv[t] = v; se[t] = e; __syncthreads();
+    if (t == 0) {
+        long long cv = 0, ce = 0; const long long rem = ctl->krem;
+        int seg = 0;
+        for (; seg < 1024; ++seg) { if (ce + se[seg] >= rem) break; cv += sv[seg]; ce += se[seg]; }
+        for (int c = seg * per; c < min(nchunks, (seg + 1) * per); ++c) {
+            if (ce + cnt_eq[c] >= rem) { ctl->chunk = c; ctl->valid_before = cv; ctl->eq_before = ce; return; }
+            cv += cnt_valid[c]; ce += cnt_eq[c];
+        }
+        ctl->chunk = -1;
+    }
+}
+// one thread walks the located chunk (4096 keys), applies the reference's index quirk and updates the stateful threshold
+__global__ void ohem_threshold_kernel(OhemCtl* ctl, const unsigned* __restrict__ vkey, const float* __restrict__ prob, int64_t npix,
+                                      float* __restrict__ thr_state) {
+    if (ctl->do_select && ctl->chunk >= 0) {
+        const unsigned target = ctl->prefix;
+        long long need = ctl->krem - ctl->eq_before, j = ctl->valid_before;
+        const int64_t base = (int64_t)ctl->chunk * OHEM_CHUNK;
+        for (int e = 0; e < OHEM_CHUNK && base + e < npix; ++e) {
+            const unsigned key = vkey[base + e];
+            if (key == target && --need == 0) break;
+            j += key != 0xFFFFFFFFu;
+        }
+        ctl->j = j;
+        const float cand = prob[j];               // sic: index among the valid pixels applied to the all-pixel vector
+        if (cand > *thr_state) *thr_state = cand;
+    }
+    ctl->thr = *thr_state;
+}
+
+// masked mean of the NLL: kept = valid && (!do_select || prob < thr)
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ prob, const float* __restrict__ nll,
+        const unsigned* __restrict__ vkey, const OhemCtl* ctl, int64_t npix, float* __restrict__ psum, unsigned* __restrict__ pcnt) {
+    const int sel = ctl->do_select; const float thr = ctl->thr;
+    float s = 0.f; unsigned n = 0;
+    const int64_t per = cdiv(npix, gridDim.x), beg = blockIdx.x * per, end = min(npix, beg + per);
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+        const bool keep = vkey[i] != 0xFFFFFFFFu && (!sel || prob[i] < thr);
+        if (keep) { s += nll[i]; ++n; }
+    }
+    __shared__ float ss[256]; __shared__ unsigned sn[256];
+    ss[threadIdx.x] = s; sn[threadIdx.x] = n; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) { ss[threadIdx.x] += ss[threadIdx.x + o]; sn[threadIdx.x] += sn[threadIdx.x + o]; } __syncthreads(); }
+    if (threadIdx.x == 0) { psum[blockIdx.x] = ss[0]; pcnt[blockIdx.x] = sn[0]; }
+}
+__global__ void ce_finalize_kernel(OhemCtl* ctl, const float* __restrict__ psum, const unsigned* __restrict__ pcnt, int nb, float* __restrict__ loss) {
+    double s = 0.0; long long n = 0;
+    for (int b = 0; b < nb; ++b) { s += psum[b]; n += pcnt[b]; }
+    ctl->kept = n; ctl->loss_sum = (float)s;
+    loss[0] = (float)(s / (double)n);            // mean over an empty selection is NaN, as torch
+}
+
+// dlogits = gout * (softmax - onehot) * keep / kept
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logits, Strides s, const long long* __restrict__ labels,
+        const float* __restrict__ prob, const OhemCtl* ctl, const float* __restrict__ gout, T* __restrict__ dlogits, Strides so,
+        int64_t npix, int H, int W, int C, long long ignore) {
+    const int sel = ctl->do_select; const float thr = ctl->thr;
+    const float g = gout[0] / (float)ctl->kept;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const T* p = logits + pix_off(i, H, W, s);
+        T* d = dlogits + pix_off(i, H, W, so);
+        const long long lab = labels[i];
+        const bool keep = lab != ignore && (!sel || prob[i] < thr);
+        if (!keep) { for (int c = 0; c < C; ++c) d[c * so.c] = from_f<T>(0.f); continue; }
+        float mx, sum; softmax_stats(p, s.c, C, mx, sum);
+        const float inv = 1.f / sum;
+        for (int c = 0; c < C; ++c) d[c * so.c] = from_f<T>(g * (expf(to_f(p[c * s.c]) - mx) * inv - (c == lab ? 1.f : 0.f)));
+    }
+}
+
+// ------------------------------------------------------------------ Dice / Tversky sums:  sums[b][c] = {sum p*[y=c], sum p, #[y=c]}
+template <typename T>
+__global__ __launch_bounds__(256) void dice_sums_kernel(const T* __restrict__ probs, Strides s, const long long* __restrict__ labels,
+                                                        float* __restrict__ partial, int H, int W, int C) {
+    extern __shared__ float sh[];                 // [C][3] per block
+    const int b = blockIdx.y; const int64_t hw = (int64_t)H * W;
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) sh[i] = 0.f;
+    __syncthreads();
+    const int64_t per = cdiv(hw, gridDim.x), beg = blockIdx.x * per, end = min(hw, beg + per);
+    for (int c = 0; c < C; ++c) {
+        float tp = 0.f, sp = 0.f, cnt = 0.f;
+        for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+            const float p = to_f(probs[b * s.n + (i / W) * s.h + (i % W) * s.w + c * s.c]);
+            const bool hit = labels[b * hw + i] == c;
+            sp += p; if (hit) { tp += p; cnt += 1.f; }
+        }
+        tp = wave_sum(tp); sp = wave_sum(sp); cnt = wave_sum(cnt);
+        __shared__ float w3[4][3];
+        if ((threadIdx.x & 63) == 0) { w3[threadIdx.x >> 6][0] = tp; w3[threadIdx.x >> 6][1] = sp; w3[threadIdx.x >> 6][2] = cnt; }
+        __syncthreads();
+        if (threadIdx.x < 3) sh[c * 3 + threadIdx.x] = w3[0][threadIdx.x] + w3[1][threadIdx.x] + w3[2][threadIdx.x] + w3[3][threadIdx.x];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) partial[((int64_t)b * gridDim.x + blockIdx.x) * 3 * C + i] = sh[i];
+}
+__global__ void dice_sums_final_kernel(const float* __restrict__ partial, int nb, int n3c, float* __restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= n3c) return;
+    float s = 0.f;
+    for (int k = 0; k < nb; ++k) s += partial[((int64_t)b * nb + k) * n3c + i];
+    sums[(int64_t)b * n3c + i] = s;
+}
+// dprobs[b,c,pix] = gout * (coef_hit[b][c] * [y=c] + coef_all[b][c])
+template <typename T>
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const long long* __restrict__ labels, const float* __restrict__ coef_hit,
+        const float* __restrict__ coef_all, const float* __restrict__ gout, T* __restrict__ dprobs, Strides so, int64_t npix, int H, int W, int C) {
+    const float g = gout[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / ((int64_t)H * W);
+        T* d = dprobs + pix_off(i, H, W, so);
+        const long long lab = labels[i];
+        for (int c = 0; c < C; ++c) d[c * so.c] = from_f<T>(g * (coef_all[b * C + c] + (c == lab ? coef_hit[b * C + c] : 0.f)));
+    }
+}
+
+// ------------------------------------------------------------------ confusion matrix: cm[target*C + argmax] += 1  (int64, exact)
+template <typename T>
+__global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ logits, Strides s, const long long* __restrict__ labels,
+                                                        unsigned long long* __restrict__ cm, int64_t npix, int H, int W, int C) {
+    extern __shared__ unsigned bins[];           // C*C per block (LDS-privatised)
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) bins[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const T* p = logits + pix_off(i, H, W, s);
+        float best = to_f(p[0]); int arg = 0;
+        for (int c = 1; c < C; ++c) { const float v = to_f(p[c * s.c]); if (v > best) { best = v; arg = c; } }   // first max wins
+        const long long lab = labels[i];
+        if (lab >= 0 && lab < C) atomicAdd(&bins[(int)lab * C + arg], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) if (bins[i]) atomicAdd(&cm[i], (unsigned long long)bins[i]);
+}
+
+// ------------------------------------------------------------------ host entry points
+static inline int nblk(int64_t n, int cap) { int64_t b = cdiv(n, 256); return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
+#define CE_REDUCE_BLOCKS 1024
+
+// workspace layout helper: all regions 256-byte aligned
+extern "C" int64_t ss_ohem_ce_workspace(int64_t npix) {
+    int64_t nchunks = cdiv(npix, OHEM_CHUNK);
+    int64_t b = 256 /*ctl*/ + 3 * OHEM_BINS * 4 + 2 * ((nchunks * 4 + 255) / 256 * 256) + 2 * CE_REDUCE_BLOCKS * 4 + 1024;
+    b += 2 * ((npix * 4 + 255) / 256 * 256);     // nll, vkey
+    return b;
+}
+
+// prob: [npix] fp32 (kept by the caller for the backward), ctl_out: 256-byte device record kept for the backward,
+// thr_state: device float holding the module's stateful threshold, loss: device float.
+extern "C" int ss_ohem_ce_fwd(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,
+                              int B, int C, int H, int W, int64_t ignore_index, double min_kept, float* thr_state, float* prob,
+                              void* ctl_out, float* loss, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(logits && labels && thr_state && prob && ctl_out && loss && workspace, "ss_ohem_ce_fwd: null pointer");
+    SS_CHECK(B > 0 && C > 0 && C <= 1024 && H > 0 && W > 0 && min_kept >= 0.0 && min_kept <= 1.0, "ss_ohem_ce_fwd: bad arguments");
+    const int64_t npix = (int64_t)B * H * W;
+    SS_CHECK(ws_bytes >= ss_ohem_ce_workspace(npix), "ss_ohem_ce_fwd: workspace too small");
+    SS_CHECK(((uintptr_t)workspace & 255) == 0, "ss_ohem_ce_fwd: workspace must be 256-byte aligned");
+    const int64_t nchunks = cdiv(npix, OHEM_CHUNK);
+    char* w = (char*)workspace;
+    OhemCtl* ctl = (OhemCtl*)w; w += 256;
+    unsigned* hist = (unsigned*)w; w += 3 * OHEM_BINS * 4;
+    unsigned* cntv = (unsigned*)w; w += (nchunks * 4 + 255) / 256 * 256;
+    unsigned* cnte = (unsigned*)w; w += (nchunks * 4 + 255) / 256 * 256;
+    float* psum = (float*)w; w += CE_REDUCE_BLOCKS * 4;
+    unsigned* pcnt = (unsigned*)w; w += CE_REDUCE_BLOCKS * 4;
+    w = (char*)workspace + (((w - (char*)workspace) + 255) / 256 * 256);
+    float* nll = (float*)w; w += (npix * 4 + 255) / 256 * 256;
+    unsigned* vkey = (unsigned*)w;
+    Strides s{sn, sc, sh, sw};
+    SS_HIP(hipMemsetAsync(workspace, 0, 256 + 3 * OHEM_BINS * 4, stream));
+    const int gb = nblk(npix, 4096);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((ce_prob_kernel<T>), dim3(gb), dim3(256), 0, stream, (const T*)logits, s, (const long long*)labels, prob, nll,
+                                          vkey, ctl, npix, H, W, C, (long long)ignore_index));
+    hipLaunchKernelGGL(ohem_plan_kernel, dim3(1), dim3(1), 0, stream, ctl, min_kept);
+    for (int pass = 0; pass < 3; ++pass) {
+        hipLaunchKernelGGL(ohem_hist_kernel, dim3(gb < 1024 ? gb : 1024), dim3(256), 0, stream, vkey, npix, ctl, hist + pass * OHEM_BINS, pass);
+        hipLaunchKernelGGL(ohem_scan_kernel, dim3(1), dim3(1), 0, stream, ctl, hist + pass * OHEM_BINS, pass);
+    }
+    hipLaunchKernelGGL(ohem_chunk_count_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, vkey, npix, ctl, cntv, cnte);
+    hipLaunchKernelGGL(ohem_locate_chunk_kernel, dim3(1), dim3(1024), 0, stream, ctl, cntv, cnte, (int)nchunks);
+    hipLaunchKernelGGL(ohem_threshold_kernel, dim3(1), dim3(1), 0, stream, ctl, vkey, prob, npix, thr_state);
+    const int rb = (int)(cdiv(npix, 1024) < CE_REDUCE_BLOCKS ? cdiv(npix, 1024) : CE_REDUCE_BLOCKS);
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(rb), dim3(256), 0, stream, prob, nll, vkey, ctl, npix, psum, pcnt);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, stream, ctl, psum, pcnt, rb, loss);
+    SS_LAUNCH_CHECK();
+    SS_HIP(hipMemcpyAsync(ctl_out, ctl, 256, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+extern "C" int ss_ohem_ce_bwd(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,
+                              const float* prob, const void* ctl, const float* gout, void* dlogits, int64_t on, int64_t oc, int64_t oh,
+                              int64_t ow, int B, int C, int H, int W, int64_t ignore_index, hipStream_t stream) {
+    SS_CHECK(logits && labels && prob && ctl && gout && dlogits && B > 0 && C > 0 && H > 0 && W > 0, "ss_ohem_ce_bwd: bad arguments");
+    const int64_t npix = (int64_t)B * H * W;
+    Strides s{sn, sc, sh, sw}, so{on, oc, oh, ow};
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(nblk(npix, 8192)), dim3(256), 0, stream, (const T*)logits, s, (const long long*)labels,
+                                          prob, (const OhemCtl*)ctl, gout, (T*)dlogits, so, npix, H, W, C, (long long)ignore_index));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// sums: [B][C][3] fp32.  workspace >= B*64*3*C floats.
+extern "C" int ss_dice_sums(int dtype, const void* probs, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels, int B,
+                            int C, int H, int W, float* sums, float* workspace, int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(probs && labels && sums && workspace && B > 0 && C > 0 && C <= 1024 && H > 0 && W > 0, "ss_dice_sums: bad arguments");
+    const int nb = (int)(cdiv((int64_t)H * W, 4096) < 64 ? cdiv((int64_t)H * W, 4096) : 64);
+    SS_CHECK(ws_bytes >= (int64_t)B * nb * 3 * C * 4, "ss_dice_sums: workspace too small");
+    Strides s{sn, sc, sh, sw};
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((dice_sums_kernel<T>), dim3(nb, B), dim3(256), 3 * C * sizeof(float), stream, (const T*)probs, s,
+                                          (const long long*)labels, workspace, H, W, C));
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dice_sums_final_kernel, dim3((unsigned)cdiv(3 * C, 256), B), dim3(256), 0, stream, workspace, nb, 3 * C, sums);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_dice_bwd(int dtype, const int64_t* labels, const float* coef_hit, const float* coef_all, const float* gout, void* dprobs,
+                           int64_t on, int64_t oc, int64_t oh, int64_t ow, int B, int C, int H, int W, hipStream_t stream) {
+    SS_CHECK(labels && coef_hit && coef_all && gout && dprobs && B > 0 && C > 0 && H > 0 && W > 0, "ss_dice_bwd: bad arguments");
+    const int64_t npix = (int64_t)B * H * W;
+    Strides so{on, oc, oh, ow};
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((dice_bwd_kernel<T>), dim3(nblk(npix, 8192)), dim3(256), 0, stream, (const long long*)labels, coef_hit,
+                                          coef_all, gout, (T*)dprobs, so, npix, H, W, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// cm: int64 [C][C] (rows = target, cols = prediction), accumulated in place
+extern "C" int ss_confusion_update(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,
+                                   int64_t* cm, int B, int C, int H, int W, hipStream_t stream) {
+    SS_CHECK(logits && labels && cm && B > 0 && C > 0 && C <= 100 && H > 0 && W > 0, "ss_confusion_update: bad arguments (C <= 100)");
+    const int64_t npix = (int64_t)B * H * W;
+    Strides s{sn, sc, sh, sw};
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((confusion_kernel<T>), dim3(nblk(npix, 2048)), dim3(256), (size_t)C * C * sizeof(unsigned), stream,
+                                          (const T*)logits, s, (const long long*)labels, (unsigned long long*)cm, npix, H, W, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}

@@ -149,7 +149,7 @@ extern "C" int ss_layernorm_bwd(int dtype, const void* dy, const void* x, const 
         else hipLaunchKernelGGL((layernorm_bwd_kernel<T, 2>), dim3(blocks), dim3(256), shm, stream, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, workspace, rows, C, lpr);
     });
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(2 * C, 256), 1), dim3(256), 0, stream, workspace, blocks, 2 * C, 1.f, dgamma, 0);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(2 * C, 32), 1), dim3(256), 0, stream, workspace, blocks, 2 * C, 1.f, dgamma, 0);
     SS_LAUNCH_CHECK();
     return 0;
 }
@@ -176,7 +176,7 @@ extern "C" int ss_colsum(int dtype, const void* x, int64_t ld, int64_t rows, int
         hipLaunchKernelGGL((colreduce_partial_kernel<ColSumF<T>>), dim3(g.nb, groups), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
     });
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(C, 256), groups), dim3(256), 0, stream, workspace, g.nb, C, scale, out, accumulate);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(C, 32), groups), dim3(256), 0, stream, workspace, g.nb, C, scale, out, accumulate);
     SS_LAUNCH_CHECK();
     return 0;
 }
@@ -355,6 +355,62 @@ extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, 
         hipLaunchKernelGGL((bn_bwd_dz_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)dy, ldd, (const T*)z, ldz, stats, gamma, beta,
                            mask, rows_per_image, coef, (T*)dz, ldo, rows, C, act);
     });
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ helpers for narrow / sliced tensors
+// column sums of a narrow matrix (C <= 32, any C): out[c] = sum_r x[r][c]   (e.g. the bias gradient of the nc-class classifier)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__ x, int64_t ld, int64_t rows, int C, float* __restrict__ partial) {
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) if (c < C) acc[c] += to_f(x[r * ld + c]);
+    }
+    __shared__ float sh[4][32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { float v = wave_sum(acc[c]); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][c] = v; }
+    __syncthreads();
+    if (threadIdx.x < C) partial[(int64_t)blockIdx.x * C + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+extern "C" int ss_colsum_small(int dtype, const void* x, int64_t ld, int64_t rows, int C, float* out, float* workspace, int64_t ws_bytes,
+                               hipStream_t stream) {
+    SS_CHECK(x && out && workspace && rows > 0 && C > 0 && C <= 32 && ld >= C, "ss_colsum_small: need 0 < C <= 32");
+    int nb = (int)(cdiv(rows, 256 * 8) < 512 ? cdiv(rows, 256 * 8) : 512);
+    if (nb < 1) nb = 1;
+    SS_CHECK(ws_bytes >= (int64_t)nb * C * 4, "ss_colsum_small: workspace too small");
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((colsum_small_kernel<T>), dim3(nb), dim3(256), 0, stream, (const T*)x, ld, rows, C, workspace));
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(C, 32), 1), dim3(256), 0, stream, workspace, nb, C, 1.f, out, 0);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[r][c] = sum_{k < nslices} x[r][k*slice_stride + c] + bvec[r / rows_per_image][c]     (gradient fan-in of concat slices)
+template <typename T>
+__global__ __launch_bounds__(256) void sum_slices_kernel(const T* __restrict__ x, int64_t ld, int nslices, int slice_stride,
+        const float* __restrict__ bvec, int64_t rows_per_image, T* __restrict__ out, int64_t rows, int C) {
+    const int chunks = C / 8; const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks; const int c = (int)(i % chunks) * 8;
+        F8 acc = bvec ? load8(bvec + (r / rows_per_image) * C + c) : zero8();
+        for (int k = 0; k < nslices; ++k) { F8 v = load8(x + r * ld + (int64_t)k * slice_stride + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc.v[e] += v.v[e]; }
+        store8(out + r * C + c, acc);
+    }
+}
+extern "C" int ss_sum_slices(int dtype, const void* x, int64_t ld, int nslices, int slice_stride, const float* bvec, int64_t rows_per_image,
+                             void* out, int64_t rows, int C, hipStream_t stream) {
+    SS_CHECK(x && out && rows > 0 && C > 0 && C % 8 == 0 && nslices > 0 && slice_stride % 8 == 0 && ld % 8 == 0 &&
+             ld >= (int64_t)(nslices - 1) * slice_stride + C && (!bvec || rows_per_image > 0), "ss_sum_slices: bad arguments");
+    int64_t total = rows * (C / 8);
+    int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((sum_slices_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)x, ld, nslices, slice_stride, bvec,
+                                          rows_per_image, (T*)out, rows, C));
     SS_LAUNCH_CHECK();
     return 0;
 }

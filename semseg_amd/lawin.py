@@ -1,0 +1,335 @@
+"""Lawin head on the MI355X kernels.
+
+Same constructors / forward signatures / ``state_dict`` layout as the reference ``modules/lawin.py`` (MLP :7-15,
+PatchEmbed :18-35, LawinAttn :39-94, ConvModule :97-105, LawinHead :109-229).  ``LawinHead.forward`` is ONE autograd
+Function whose forward and backward are explicit kernel sequences over channels-last activations:
+
+* no unfold: each ratio's context windows are 8x8 gathers from one pooled grid (``ops.lawin_pool_fwd``);
+* concatenations are channel slices of pre-allocated buffers that GEMM / BN / bilinear kernels write in place;
+* ``cat`` commutes the 1x1 conv with the bilinear x2 up-sampling (both linear): the 5E->E GEMM runs at S/8 and its
+  E-channel result is up-sampled, instead of up-sampling five E-channel maps and running the GEMM at S/4
+  (4x fewer FLOPs, no [B,5E,S/4,S/4] tensor; exact in real arithmetic, rounding reordered);
+* BatchNorm uses batch statistics in training (running buffers updated by the finalize kernel) and running statistics in
+  eval; Mish and the Dropout2d multiplier are fused into the BN-apply kernels.
+"""
+import torch
+from torch import nn, Tensor
+import torch.nn.functional as tnf
+
+from . import ops
+from .runtime import compute_dtype_for, as_tokens_nhwc
+from .segformer import w_fwd, w_bwd
+from .shapes import LAWIN_BRANCHES
+
+
+def _conv_w(w, dtype):
+    """1x1 conv weight [O, I, 1, 1] -> [O, I] in the compute dtype."""
+    return w_fwd(w, dtype)
+
+
+def _bn_stats(z, P, Bf, prefix, training):
+    if training:
+        return ops.bn_stats(z, 1e-5, 0.1, Bf[prefix + '.running_mean'], Bf[prefix + '.running_var'], Bf[prefix + '.num_batches_tracked'])
+    return ops.bn_eval_stats(Bf[prefix + '.running_mean'], Bf[prefix + '.running_var'])
+
+
+def _nchw_view(tok, B, H, W):
+    return tok.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def head_forward(P, Bf, feats, E, training, drop_mask):
+    """feats: 4 NCHW-shaped maps (S/4..S/32).  -> logits tokens [B*H4*W4, nc], saved state."""
+    T = compute_dtype_for(feats[0])
+    B = feats[0].shape[0]
+    dims = [f.shape[1] for f in feats]
+    hw = [(f.shape[2], f.shape[3]) for f in feats]
+    (H4, W4), (H8, W8) = hw[0], hw[1]
+    if H8 % 8 or W8 % 8:
+        raise ValueError(f'LawinHead: the S/8 map must be a multiple of 8 (got {H8}x{W8}); input tiles must be multiples of 64')
+    t = [as_tokens_nhwc(f.detach(), T) for f in feats]
+    R8, R4, inter = B * H8 * W8, B * H4 * W4, max(E // 2, 1)
+    dev = t[0].device
+    S = {'t': t, 'hw': hw, 'dims': dims, 'T': T, 'B': B}
+
+    # per-level linear embeddings -> [c4, c3, c2] concat at S/8 -> linear_fuse
+    cat3 = torch.empty((R8, 3 * E), dtype=T, device=dev)
+    ops.gemm_nt(t[1], w_fwd(P['linear_c2.proj.weight'], T), bias=P['linear_c2.proj.bias'], out=cat3[:, 2 * E:])
+    for lvl, sl in ((2, slice(E, 2 * E)), (3, slice(0, E))):
+        cs = ops.gemm_nt(t[lvl], w_fwd(P[f'linear_c{lvl + 1}.proj.weight'], T), bias=P[f'linear_c{lvl + 1}.proj.bias'])
+        ops.bilinear_fwd(cs, B, hw[lvl][0], hw[lvl][1], H8, W8, out=cat3[:, sl])
+    zf = ops.gemm_nt(cat3, _conv_w(P['linear_fuse.conv.weight'], T))
+    stf = _bn_stats(zf, P, Bf, 'linear_fuse.bn', training)
+    cat5 = torch.empty((R8, 5 * E), dtype=T, device=dev)
+    feat = ops.bn_apply(zf, stf, P['linear_fuse.bn.weight'], P['linear_fuse.bn.bias'], act=1, out=cat5[:, :E])
+    S.update(cat3=cat3, zf=zf, stf=stf, cat5=cat5)
+
+    # three large-window attention branches
+    S['br'] = []
+    for k, (r, heads) in enumerate(LAWIN_BRANCHES):
+        p = f'lawin_{r}'
+        G, amax = ops.lawin_pool_fwd(feat, B, H8, W8, r)
+        Wm = torch.stack([P[f'{p}.position_mixing.{i}.weight'].detach() for i in range(heads)]).contiguous()
+        bm = torch.stack([P[f'{p}.position_mixing.{i}.bias'].detach() for i in range(heads)]).contiguous()
+        ctx = ops.lawin_mix(Wm, bm, B, H8, W8, r, heads, G=G)
+        wpg = torch.cat([P[f'{p}.phi.weight'].detach().reshape(inter, E), P[f'{p}.g.weight'].detach().reshape(inter, E)])
+        bpg = torch.cat([P[f'{p}.phi.bias'].detach(), P[f'{p}.g.bias'].detach()])
+        pg = ops.gemm_nt(ctx, w_fwd(wpg, T), bias=bpg)
+        th = ops.gemm_nt(feat, _conv_w(P[f'{p}.theta.weight'], T), bias=P[f'{p}.theta.bias'])
+        y, lse = ops.lawin_attn_fwd(th, pg, B, H8, W8, heads)
+        z = ops.gemm_nt(y, _conv_w(P[f'{p}.conv_out.0.weight'], T))
+        st = _bn_stats(z, P, Bf, f'{p}.conv_out.1', training)
+        ops.bn_apply(z, st, P[f'{p}.conv_out.1.weight'], P[f'{p}.conv_out.1.bias'], act=0, res=feat, out=cat5[:, (k + 1) * E:(k + 2) * E])
+        S['br'].append(dict(G=G, amax=amax, Wm=Wm, ctx=ctx, wpg=wpg, pg=pg, th=th, y=y, lse=lse, z=z, st=st))
+
+    # image-pool branch: GAP -> ConvModule -> broadcast (bilinear of a 1x1 map)
+    gp = ops.cast(ops.colsum(feat, groups=B, scale=1.0 / (H8 * W8)), T)
+    zp = ops.gemm_nt(gp, _conv_w(P['image_pool.1.conv.weight'], T))
+    stp = _bn_stats(zp, P, Bf, 'image_pool.1.bn', training)
+    ap = ops.bn_apply(zp, stp, P['image_pool.1.bn.weight'], P['image_pool.1.bn.bias'], act=1)
+    ops.bcast_rows(ap, cat5[:, 4 * E:], H8 * W8)
+    S.update(gp=gp, zp=zp, stp=stp)
+
+    # cat: 1x1 conv at S/8, bilinear x2, BN + Mish at S/4; low-level fuse; classifier
+    z8 = ops.gemm_nt(cat5, _conv_w(P['cat.conv.weight'], T))
+    z4 = ops.bilinear_fwd(z8, B, H8, W8, H4, W4)
+    stc = _bn_stats(z4, P, Bf, 'cat.bn', training)
+    cat2 = torch.empty((R4, E + 48), dtype=T, device=dev)
+    ops.bn_apply(z4, stc, P['cat.bn.weight'], P['cat.bn.bias'], act=1, out=cat2[:, :E])
+    ops.gemm_nt(t[0], w_fwd(P['linear_c1.proj.weight'], T), bias=P['linear_c1.proj.bias'], out=cat2[:, E:])
+    zl = ops.gemm_nt(cat2, _conv_w(P['low_level_fuse.conv.weight'], T))
+    stl = _bn_stats(zl, P, Bf, 'low_level_fuse.bn', training)
+    fused = ops.bn_apply(zl, stl, P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'], act=1, mask=drop_mask,
+                         rows_per_image=H4 * W4 if drop_mask is not None else 0)
+    seg = ops.gemm_nt(fused, _conv_w(P['linear_pred.weight'], T), bias=P['linear_pred.bias'])
+    S.update(z4=z4, stc=stc, cat2=cat2, zl=zl, stl=stl, fused=fused, drop_mask=drop_mask, training=training)
+    return seg, S
+
+
+def head_backward(P, S, dseg, E):
+    """dseg: [B*H4*W4, nc] -> (grads of the 4 feature token matrices, {param: grad})."""
+    T, B, t, hw = S['T'], S['B'], S['t'], S['hw']
+    (H4, W4), (H8, W8) = hw[0], hw[1]
+    inter, training, G = max(E // 2, 1), S['training'], {}
+    mask = S['drop_mask']
+    rpi4 = H4 * W4 if mask is not None else 0
+
+    def bn_grads(prefix, dgb):
+        G[prefix + '.weight'], G[prefix + '.bias'] = dgb[0], dgb[1]
+
+    # classifier + low-level fuse
+    G['linear_pred.weight'] = ops.gemm_tn(dseg, S['fused'])
+    G['linear_pred.bias'] = ops.colsum_any(dseg)
+    dfused = ops.gemm_nt(dseg, w_bwd(P['linear_pred.weight'], T))
+    dzl, dgb = ops.bn_bwd(dfused, S['zl'], S['stl'], P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'], act=1, mask=mask,
+                          rows_per_image=rpi4, training=training)
+    bn_grads('low_level_fuse.bn', dgb)
+    G['low_level_fuse.conv.weight'] = ops.gemm_tn(dzl, S['cat2'])
+    dcat2 = ops.gemm_nt(dzl, w_bwd(P['low_level_fuse.conv.weight'], T))
+    dc1 = dcat2[:, E:]
+    G['linear_c1.proj.weight'] = ops.gemm_tn(dc1, t[0])
+    G['linear_c1.proj.bias'] = ops.colsum(dc1)[0]
+    dt = [ops.gemm_nt(dc1, w_bwd(P['linear_c1.proj.weight'], T)), None, None, None]
+    # cat
+    dz4, dgb = ops.bn_bwd(dcat2[:, :E], S['z4'], S['stc'], P['cat.bn.weight'], P['cat.bn.bias'], act=1, training=training)
+    bn_grads('cat.bn', dgb)
+    dz8 = ops.bilinear_bwd(dz4, B, H8, W8, H4, W4)
+    G['cat.conv.weight'] = ops.gemm_tn(dz8, S['cat5'])
+    dcat5 = ops.gemm_nt(dz8, w_bwd(P['cat.conv.weight'], T))
+    feat = S['cat5'][:, :E]
+    # image-pool branch
+    dap = ops.cast(ops.colsum(dcat5[:, 4 * E:], groups=B), T)
+    dzp, dgb = ops.bn_bwd(dap, S['zp'], S['stp'], P['image_pool.1.bn.weight'], P['image_pool.1.bn.bias'], act=1, training=training)
+    bn_grads('image_pool.1.bn', dgb)
+    G['image_pool.1.conv.weight'] = ops.gemm_tn(dzp, S['gp'])
+    dgp = ops.gemm_nt(dzp, w_bwd(P['image_pool.1.conv.weight'], T), out_f32=(T != torch.float32))
+    # gradient fan-in on feat: short path + the three residuals + broadcast of the pooled branch (scaled by 1/(H8*W8))
+    pool_vec = _scaled(dgp, 1.0 / (H8 * W8))
+    acc = ops.sum_slices(dcat5, 4, E, E, bvec=pool_vec, rows_per_image=H8 * W8)
+    dGs, amaxs = [], []
+    for k, (r, heads) in enumerate(LAWIN_BRANCHES):
+        p, br = f'lawin_{r}', S['br'][k]
+        dz, dgb = ops.bn_bwd(dcat5[:, (k + 1) * E:(k + 2) * E], br['z'], br['st'], P[f'{p}.conv_out.1.weight'], P[f'{p}.conv_out.1.bias'],
+                             act=0, training=training)
+        bn_grads(f'{p}.conv_out.1', dgb)
+        G[f'{p}.conv_out.0.weight'] = ops.gemm_tn(dz, br['y'])
+        dy = ops.gemm_nt(dz, w_bwd(P[f'{p}.conv_out.0.weight'], T))
+        dth, dpg = ops.lawin_attn_bwd(br['th'], br['pg'], br['y'], dy, br['lse'], B, H8, W8, heads)
+        G[f'{p}.theta.weight'] = ops.gemm_tn(dth, feat)
+        G[f'{p}.theta.bias'] = ops.colsum(dth)[0]
+        acc = ops.gemm_nt(dth, w_bwd(P[f'{p}.theta.weight'], T), res=acc)
+        dwpg = ops.gemm_tn(dpg, br['ctx'])
+        dbpg = ops.colsum(dpg)[0]
+        G[f'{p}.phi.weight'], G[f'{p}.g.weight'] = dwpg[:inter], dwpg[inter:]
+        G[f'{p}.phi.bias'], G[f'{p}.g.bias'] = dbpg[:inter], dbpg[inter:]
+        dctxp = ops.gemm_nt(dpg, ops.transpose_cast(br['wpg'].contiguous(), T))
+        dWb = ops.lawin_mix_wgrad(br['G'], dctxp, B, H8, W8, r, heads)
+        for i in range(heads):
+            G[f'{p}.position_mixing.{i}.weight'] = dWb[i, :, :64]
+            G[f'{p}.position_mixing.{i}.bias'] = dWb[i, :, 64]
+        dctx = ops.lawin_mix(br['Wm'], None, B, H8, W8, r, heads, xwin=dctxp, transpose=True)
+        dGs.append(ops.lawin_gather_bwd(dctx, B, H8, W8, r))
+        amaxs.append(br['amax'])
+    dfeat = ops.lawin_pool_bwd(dGs, amaxs, B, H8, W8, E, T, base=acc)
+    # linear_fuse and the per-level embeddings
+    dzf, dgb = ops.bn_bwd(dfeat, S['zf'], S['stf'], P['linear_fuse.bn.weight'], P['linear_fuse.bn.bias'], act=1, training=training)
+    bn_grads('linear_fuse.bn', dgb)
+    G['linear_fuse.conv.weight'] = ops.gemm_tn(dzf, S['cat3'])
+    dcat3 = ops.gemm_nt(dzf, w_bwd(P['linear_fuse.conv.weight'], T))
+    for lvl, sl in ((1, slice(2 * E, 3 * E)), (2, slice(E, 2 * E)), (3, slice(0, E))):
+        d = dcat3[:, sl]
+        if lvl > 1:
+            d = ops.bilinear_bwd(d, B, hw[lvl][0], hw[lvl][1], H8, W8)
+        name = f'linear_c{lvl + 1}.proj'
+        G[name + '.weight'] = ops.gemm_tn(d, t[lvl])
+        G[name + '.bias'] = ops.colsum(d)[0]
+        dt[lvl] = ops.gemm_nt(d, w_bwd(P[name + '.weight'], T))
+    return dt, G
+
+
+def _scaled(v, s):
+    """tiny [B, E] fp32 vector * scalar (host-side plumbing on B*E elements)."""
+    return (v.float() * s).contiguous()
+
+
+class LawinHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, drop_mask, names, x1, x2, x3, x4, *params):
+        P = dict(zip(names, params))
+        Bf = dict(module.named_buffers())
+        seg, S = head_forward(P, Bf, (x1, x2, x3, x4), module.embed_dim, module.training, drop_mask)
+        ctx.S, ctx.names, ctx.params, ctx.E = S, names, params, module.embed_dim
+        B, (H4, W4) = S['B'], S['hw'][0]
+        return _nchw_view(seg, B, H4, W4)
+
+    @staticmethod
+    def backward(ctx, dout):
+        S = ctx.S
+        P = dict(zip(ctx.names, ctx.params))
+        dseg = as_tokens_nhwc(dout, S['T'])
+        dt, G = head_backward(P, S, dseg.contiguous(), ctx.E)
+        ctx.S = None
+        B, hw = S['B'], S['hw']
+        dfe = [(_nchw_view(d, B, h, w) if ctx.needs_input_grad[3 + i] else None) for i, (d, (h, w)) in enumerate(zip(dt, hw))]
+        grads = [G.get(n) for n in ctx.names]
+        grads = [g if g is None else g.reshape(p.shape) for g, p in zip(grads, ctx.params)]
+        return (None, None, None, *dfe, *grads)
+
+
+# ------------------------------------------------------------------ modules (reference API)
+class MLP(nn.Module):
+    def __init__(self, dim=2048, embed_dim=768):
+        super().__init__()
+        self.proj = nn.Linear(dim, embed_dim)
+
+    def forward(self, x: Tensor) -> Tensor:
+        from .segformer import _ParamFn
+
+        class _Fn(_ParamFn):
+            @staticmethod
+            def fwd(P, t, meta):
+                return ops.gemm_nt(t, w_fwd(P['proj.weight'], t.dtype), bias=P['proj.bias']), {'t': t}
+
+            @staticmethod
+            def bwd(P, S, dy, meta):
+                return ops.gemm_nt(dy, w_bwd(P['proj.weight'], dy.dtype)), {'proj.weight': ops.gemm_tn(dy, S['t']), 'proj.bias': ops.colsum_any(dy)}
+
+        b, c, h, w = x.shape
+        return _Fn.run(as_tokens_nhwc(x, compute_dtype_for(x)), None, self).view(b, h * w, -1)
+
+
+class PatchEmbed(nn.Module):
+    """0.5 * (max_pool + avg_pool) with right/bottom zero padding (modules/lawin.py:18-35).  API-compatibility module:
+    LawinHead never calls it (its pooled-context kernel subsumes it); standalone calls use torch pooling."""
+
+    def __init__(self, patch_size=4) -> None:
+        super().__init__()
+        self.patch_size = patch_size
+        self.proj = nn.ModuleList([nn.MaxPool2d(patch_size, patch_size), nn.AvgPool2d(patch_size, patch_size)])
+
+    def forward(self, x: Tensor) -> Tensor:
+        _, _, h, w = x.shape
+        if w % self.patch_size != 0:
+            x = tnf.pad(x, (0, self.patch_size - w % self.patch_size))
+        if h % self.patch_size != 0:
+            x = tnf.pad(x, (0, 0, 0, self.patch_size - h % self.patch_size))
+        return 0.5 * (self.proj[0](x) + self.proj[1](x))
+
+
+class LawinAttn(nn.Module):
+    """Parameter container with the reference layout (modules/lawin.py:39-55); computed inside LawinHeadFn."""
+
+    def __init__(self, in_ch=512, head=4, patch_size=8, reduction=2) -> None:
+        super().__init__()
+        self.head = head
+        self.position_mixing = nn.ModuleList([nn.Linear(patch_size * patch_size, patch_size * patch_size) for _ in range(self.head)])
+        self.inter_channels = max(in_ch // reduction, 1)
+        self.g = nn.Conv2d(in_ch, self.inter_channels, (1, 1))
+        self.theta = nn.Conv2d(in_ch, self.inter_channels, (1, 1))
+        self.phi = nn.Conv2d(in_ch, self.inter_channels, (1, 1))
+        self.conv_out = nn.Sequential(nn.Conv2d(self.inter_channels, in_ch, (1, 1), bias=False), nn.BatchNorm2d(in_ch))
+
+
+class ConvModule(nn.Module):
+    """1x1 conv (no bias) -> BatchNorm2d -> Mish (modules/lawin.py:97-105)."""
+
+    def __init__(self, c1, c2):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, (1, 1), bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.activate = nn.Mish(True)
+
+    def forward(self, x: Tensor) -> Tensor:
+        from .segformer import _ParamFn
+        mod = self
+
+        class _Fn(_ParamFn):
+            @staticmethod
+            def fwd(P, t, meta):
+                z = ops.gemm_nt(t, _conv_w(P['conv.weight'], t.dtype))
+                st = _bn_stats(z, P, dict(mod.named_buffers()), 'bn', mod.training)
+                return ops.bn_apply(z, st, P['bn.weight'], P['bn.bias'], act=1), {'t': t, 'z': z, 'st': st}
+
+            @staticmethod
+            def bwd(P, S, dy, meta):
+                dz, dgb = ops.bn_bwd(dy, S['z'], S['st'], P['bn.weight'], P['bn.bias'], act=1, training=mod.training)
+                return ops.gemm_nt(dz, w_bwd(P['conv.weight'], dy.dtype)), {'conv.weight': ops.gemm_tn(dz, S['t']), 'bn.weight': dgb[0], 'bn.bias': dgb[1]}
+
+        b, c, h, w = x.shape
+        y = _Fn.run(as_tokens_nhwc(x, compute_dtype_for(x)), None, self)
+        return _nchw_view(y, b, h, w)
+
+
+class LawinHead(nn.Module):
+    def __init__(self, in_channels: list, embed_dim=512, out_channels=8) -> None:
+        super().__init__()
+        if embed_dim % 128:
+            raise ValueError('LawinHead: embed_dim must be a multiple of 128 (64 heads on embed_dim/2 channels, modules/lawin.py:48,73,122)')
+        for i, dim in enumerate(in_channels):
+            self.add_module(f"linear_c{i + 1}", MLP(dim, 48 if i == 0 else embed_dim))
+        self.linear_fuse = ConvModule(embed_dim * 3, embed_dim)
+        self.lawin_8 = LawinAttn(embed_dim, 64)
+        self.lawin_4 = LawinAttn(embed_dim, 16)
+        self.lawin_2 = LawinAttn(embed_dim, 4)
+        self.ds_8, self.ds_4, self.ds_2 = PatchEmbed(8), PatchEmbed(4), PatchEmbed(2)
+        self.image_pool = nn.Sequential(nn.AdaptiveAvgPool2d(1), ConvModule(embed_dim, embed_dim))
+        self.cat = ConvModule(embed_dim * 5, embed_dim)
+        self.low_level_fuse = ConvModule(embed_dim + 48, embed_dim)
+        self.linear_pred = nn.Conv2d(embed_dim, out_channels, (1, 1))
+        self.dropout = nn.Dropout2d(0.1)
+        self.embed_dim, self.out_channels = embed_dim, out_channels
+
+    def _drop_mask(self, b, dtype, device):
+        p = self.dropout.p
+        if not self.training or p == 0.0:
+            return None
+        noise = torch.empty((b, self.embed_dim, 1, 1), dtype=dtype, device=device).bernoulli_(1 - p).div_(1 - p)   # as F.dropout2d
+        return noise.float().reshape(b, self.embed_dim).contiguous()
+
+    def forward(self, features):
+        x1, x2, x3, x4 = features
+        T = compute_dtype_for(x1)
+        if self.training and x1.shape[0] < 2:
+            raise ValueError('Expected more than 1 value per channel when training (image_pool BatchNorm on a (B,C,1,1) map needs B >= 2)')
+        names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        return LawinHeadFn.apply(self, self._drop_mask(x1.shape[0], T, x1.device), names, x1, x2, x3, x4, *params)

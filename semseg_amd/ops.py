@@ -10,7 +10,7 @@ from ._lib import lib, check
 F32, BF16 = 0, 1
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _WS = {}
-COLRED_BLOCKS = 2048
+COLRED_BLOCKS = 1024
 
 
 def dt(t):
@@ -423,4 +423,203 @@ def bcast_rows(v, out, rows_per_image):
     if ldv != C or Co != C or rows != Bv * rows_per_image or v.dtype != out.dtype:
         raise ValueError('bcast_rows: bad shapes')
     check(lib().ss_bcast_rows(dt(v), _p(v), _p(out), ldy, rows_per_image, rows, C, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------ Lawin
+def lawin_grid(H, W, r):
+    st = 8 // r
+    return (H // 8 - 1) * st + 8, (W // 8 - 1) * st + 8
+
+
+def lawin_pool_fwd(feat, B, H, W, r):
+    """feat [B*H*W, C] (row stride ld) -> G [B*gh*gw, C], amax uint8 [B*gh*gw, C]."""
+    dev = _dev(feat)
+    rows, C, ld = _mat(feat, 'feat')
+    if rows != B * H * W:
+        raise ValueError('lawin_pool_fwd: bad feat')
+    gh, gw = lawin_grid(H, W, r)
+    G = torch.empty((B * gh * gw, C), dtype=feat.dtype, device=dev)
+    amax = torch.empty((B * gh * gw, C), dtype=torch.uint8, device=dev)
+    check(lib().ss_lawin_pool_fwd(dt(feat), _p(feat), ld, _p(G), _p(amax), B, H, W, C, r, _stream()))
+    return G, amax
+
+
+def lawin_pool_bwd(dGs, amaxs, B, H, W, C, dtype, base=None):
+    """dGs/amaxs: lists for r = 8, 4, 2 -> d(feat) [B*H*W, C] (= base + pooled-context gradient)."""
+    dev = _dev(dGs[0])
+    for r, d, a in zip((8, 4, 2), dGs, amaxs):
+        gh, gw = lawin_grid(H, W, r)
+        _f32(d, 'dG', B * gh * gw * C)
+        if a.dtype != torch.uint8 or a.numel() != B * gh * gw * C or not a.is_contiguous():
+            raise ValueError('lawin_pool_bwd: bad amax')
+    ldb = 0
+    if base is not None:
+        rb, Cb, ldb = _mat(base, 'base')
+        if (rb, Cb) != (B * H * W, C) or base.dtype != dtype:
+            raise ValueError('lawin_pool_bwd: bad base')
+    out = torch.empty((B * H * W, C), dtype=dtype, device=dev)
+    check(lib().ss_lawin_pool_bwd(_DT[dtype], _p(dGs[0]), _p(dGs[1]), _p(dGs[2]), _p(amaxs[0]), _p(amaxs[1]), _p(amaxs[2]),
+                                  _p(base), ldb, _p(out), C, B, H, W, C, _stream()))
+    return out
+
+
+def lawin_gather_bwd(dctx, B, H, W, r):
+    dev = _dev(dctx)
+    nwin = B * (H // 8) * (W // 8)
+    rows, C, ld = _mat(dctx, 'dctx')
+    if rows != nwin * 64 or ld != C:
+        raise ValueError('lawin_gather_bwd: bad dctx')
+    gh, gw = lawin_grid(H, W, r)
+    dG = torch.empty((B * gh * gw, C), dtype=torch.float32, device=dev)
+    check(lib().ss_lawin_gather_bwd(dt(dctx), _p(dctx), _p(dG), B, H, W, C, r, _stream()))
+    return dG
+
+
+def lawin_mix(Wm, bm, B, H, W, r, heads, G=None, xwin=None, transpose=False):
+    """position mixing; exactly one of G (pooled grid) / xwin (window-ordered [nwin*64, C])."""
+    src = G if G is not None else xwin
+    dev = _dev(src)
+    C = src.shape[1]
+    nwin = B * (H // 8) * (W // 8)
+    gh, gw = lawin_grid(H, W, r)
+    if not src.is_contiguous() or src.shape[0] != (B * gh * gw if G is not None else nwin * 64):
+        raise ValueError('lawin_mix: bad source tensor')
+    _f32(Wm, 'Wm', heads * 4096)
+    _f32(bm, 'bm', heads * 64)
+    out = torch.empty((nwin * 64, C), dtype=src.dtype, device=dev)
+    check(lib().ss_lawin_mix(dt(src), _p(G), _p(xwin), _p(Wm), _p(bm), _p(out), B, H, W, C, r, heads, int(transpose), _stream()))
+    return out
+
+
+def lawin_mix_wgrad(G, dwin, B, H, W, r, heads):
+    """-> dWb [heads, 64, 65] fp32."""
+    dev = _dev(G)
+    C = G.shape[1]
+    nwin = B * (H // 8) * (W // 8)
+    if not G.is_contiguous() or not dwin.is_contiguous() or dwin.shape != (nwin * 64, C) or dwin.dtype != G.dtype:
+        raise ValueError('lawin_mix_wgrad: bad tensors')
+    out = torch.empty((heads, 64, 65), dtype=torch.float32, device=dev)
+    ws = workspace(dev, lib().ss_lawin_mix_wgrad_workspace(B, H, W, heads))
+    check(lib().ss_lawin_mix_wgrad(dt(G), _p(G), _p(dwin), _p(out), B, H, W, C, r, heads, _p(ws), ws.numel(), _stream()))
+    return out
+
+
+def lawin_attn_fwd(theta, pg, B, H, W, heads):
+    """theta [B*H*W, inter] (image order, row stride ld), pg [nwin*64, 2*inter] -> y [B*H*W, inter], lse [nwin, heads, 64]."""
+    dev = _dev(theta)
+    rows, inter, ldt = _mat(theta, 'theta')
+    nwin = B * (H // 8) * (W // 8)
+    if rows != B * H * W or pg.shape != (nwin * 64, 2 * inter) or not pg.is_contiguous() or pg.dtype != theta.dtype:
+        raise ValueError('lawin_attn_fwd: bad shapes')
+    y = torch.empty((rows, inter), dtype=theta.dtype, device=dev)
+    lse = torch.empty((nwin, heads, 64), dtype=torch.float32, device=dev)
+    check(lib().ss_lawin_attn_fwd(dt(theta), _p(theta), ldt, _p(pg), _p(y), inter, _p(lse), B, H, W, inter, heads, _stream()))
+    return y, lse
+
+
+def lawin_attn_bwd(theta, pg, y, dy, lse, B, H, W, heads):
+    dev = _dev(theta)
+    rows, inter, ldt = _mat(theta, 'theta')
+    _, _, ldy = _mat(y, 'y')
+    _, _, lddy = _mat(dy, 'dy')
+    if y.shape != (rows, inter) or dy.shape != (rows, inter) or dy.dtype != theta.dtype:
+        raise ValueError('lawin_attn_bwd: bad shapes')
+    dtheta = torch.empty((rows, inter), dtype=theta.dtype, device=dev)
+    dpg = torch.empty_like(pg)
+    check(lib().ss_lawin_attn_bwd(dt(theta), _p(theta), ldt, _p(pg), _p(y), ldy, _p(dy), lddy, _p(lse), _p(dtheta), inter, _p(dpg),
+                                  B, H, W, inter, heads, _stream()))
+    return dtheta, dpg
+
+
+# ------------------------------------------------------------------ losses / metrics
+def _nchw(t, name):
+    if t.dim() != 4:
+        raise ValueError(f'{name}: expected [B, C, H, W]')
+    return t.shape, t.stride()
+
+
+def ohem_ce_fwd(logits, labels, ignore_index, min_kept, thr_state):
+    """-> loss (device scalar), prob [B*H*W] fp32, ctl (256-byte device record).  thr_state is updated in place."""
+    dev = _dev(logits)
+    (B, C, H, W), (sn, sc, sh, sw) = _nchw(logits, 'logits')
+    if labels.shape != (B, H, W) or labels.dtype != torch.int64 or not labels.is_contiguous():
+        raise ValueError('ohem_ce_fwd: labels must be contiguous int64 [B, H, W]')
+    _f32(thr_state, 'thr_state', 1)
+    npix = B * H * W
+    prob = torch.empty(npix, dtype=torch.float32, device=dev)
+    ctl = torch.empty(256, dtype=torch.uint8, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    ws = workspace(dev, lib().ss_ohem_ce_workspace(npix))
+    check(lib().ss_ohem_ce_fwd(dt(logits), _p(logits), sn, sc, sh, sw, _p(labels), B, C, H, W, int(ignore_index), float(min_kept),
+                               _p(thr_state), _p(prob), _p(ctl), _p(loss), _p(ws), ws.numel(), _stream()))
+    return loss, prob, ctl
+
+
+def ohem_ce_bwd(logits, labels, prob, ctl, gout, ignore_index):
+    _dev(logits)
+    (B, C, H, W), (sn, sc, sh, sw) = _nchw(logits, 'logits')
+    dl = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
+    on, oc, oh, ow = dl.stride()
+    g = gout.reshape(1).float().contiguous()
+    check(lib().ss_ohem_ce_bwd(dt(logits), _p(logits), sn, sc, sh, sw, _p(labels), _p(prob), _p(ctl), _p(g), _p(dl), on, oc, oh, ow,
+                               B, C, H, W, int(ignore_index), _stream()))
+    return dl
+
+
+def dice_sums(probs, labels):
+    """-> sums [B, C, 3] fp32: (sum p*[y=c], sum p, #[y=c])."""
+    dev = _dev(probs)
+    (B, C, H, W), (sn, sc, sh, sw) = _nchw(probs, 'probs')
+    if labels.shape != (B, H, W) or labels.dtype != torch.int64 or not labels.is_contiguous():
+        raise ValueError('dice_sums: labels must be contiguous int64 [B, H, W]')
+    sums = torch.empty((B, C, 3), dtype=torch.float32, device=dev)
+    ws = workspace(dev, B * 64 * 3 * C * 4)
+    check(lib().ss_dice_sums(dt(probs), _p(probs), sn, sc, sh, sw, _p(labels), B, C, H, W, _p(sums), _p(ws), ws.numel(), _stream()))
+    return sums
+
+
+def dice_bwd(probs_like, labels, coef_hit, coef_all, gout):
+    _dev(probs_like)
+    B, C, H, W = probs_like.shape
+    _f32(coef_hit, 'coef_hit', B * C), _f32(coef_all, 'coef_all', B * C)
+    d = torch.empty_strided(probs_like.shape, probs_like.stride(), dtype=probs_like.dtype, device=probs_like.device)
+    on, oc, oh, ow = d.stride()
+    g = gout.reshape(1).float().contiguous()
+    check(lib().ss_dice_bwd(dt(probs_like), _p(labels), _p(coef_hit), _p(coef_all), _p(g), _p(d), on, oc, oh, ow, B, C, H, W, _stream()))
+    return d
+
+
+def confusion_update(logits, labels, cm):
+    """cm int64 [C, C] += counts of (target, argmax(logits, 1))."""
+    _dev(logits)
+    (B, C, H, W), (sn, sc, sh, sw) = _nchw(logits, 'logits')
+    if labels.shape != (B, H, W) or labels.dtype != torch.int64 or not labels.is_contiguous():
+        raise ValueError('confusion_update: labels must be contiguous int64 [B, H, W]')
+    if cm.dtype != torch.int64 or cm.shape != (C, C) or not cm.is_contiguous():
+        raise ValueError('confusion_update: cm must be contiguous int64 [C, C]')
+    check(lib().ss_confusion_update(dt(logits), _p(logits), sn, sc, sh, sw, _p(labels), _p(cm), B, C, H, W, _stream()))
+    return cm
+
+
+def colsum_any(x):
+    """[rows, C] -> [C] fp32 column sums for any C (narrow tensors use the scalar kernel)."""
+    rows, C, ld = _mat(x, 'x')
+    if C % 8 == 0 and ld % 8 == 0:
+        return colsum(x)[0]
+    dev = _dev(x)
+    out = torch.empty(C, dtype=torch.float32, device=dev)
+    ws = workspace(dev, 512 * C * 4)
+    check(lib().ss_colsum_small(dt(x), _p(x), ld, rows, C, _p(out), _p(ws), ws.numel(), _stream()))
+    return out
+
+
+def sum_slices(x, nslices, slice_stride, C, bvec=None, rows_per_image=0):
+    """out[r, :C] = sum_k x[r, k*slice_stride : k*slice_stride + C] + bvec[r // rows_per_image]."""
+    dev = _dev(x)
+    rows, _, ld = _mat(x, 'x')
+    if bvec is not None:
+        _f32(bvec, 'bvec')
+    out = torch.empty((rows, C), dtype=x.dtype, device=dev)
+    check(lib().ss_sum_slices(dt(x), _p(x), ld, nslices, slice_stride, _p(bvec), rows_per_image, _p(out), rows, C, _stream()))
     return out

@@ -120,6 +120,20 @@ def gen_head(training):
     for k in GRAD_KEYS_HEAD:
         save['grad.' + k] = np_(grads[k])
     if training:
+        # the reference's OWN bf16 path (torch.autocast) on the same inputs: its deviation from fp32 is the noise floor the
+        # bf16 GPU tests measure our deviation against (a 2e-2 budget that the reference itself misses cannot be a bar)
+        head_b = det_fill_(LawinHead(chans, 128, 6)).train()
+        head_b.dropout.p = 0.0
+        fb = [f.detach().clone().requires_grad_(True) for f in feats]
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            ob = head_b(fb)
+        (ob.float() * proj).sum().backward()
+        gb = {k: p.grad for k, p in head_b.named_parameters()}
+        save['bf16.out'] = np_(ob.float())
+        for i in range(4):
+            save[f'bf16.dfeat{i}'] = np_(fb[i].grad)
+        for k in GRAD_KEYS_HEAD:
+            save['bf16.grad.' + k] = np_(gb[k])
         after = head.state_dict()
         for k in ('linear_fuse.bn.running_mean', 'linear_fuse.bn.running_var', 'lawin_8.conv_out.1.running_var',
                   'image_pool.1.bn.running_mean', 'image_pool.1.bn.running_var', 'cat.bn.running_var',

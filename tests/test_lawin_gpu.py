@@ -1,0 +1,149 @@
+"""Lawin head + full MiT-Lawin segmentor on the GPU vs the reference golden vectors and the CPU oracle."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from semseg_amd.detinit import det_fill_, det_input, det_labels, det_state_dict
+from semseg_amd import shapes
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+CH = [32, 64, 160, 256]
+
+
+def grad_close(params, key, ref, ref_of, tol):
+    """max-abs error of a parameter gradient relative to max|ref|.  A bias that feeds a training-mode BatchNorm (or the
+    softmax-invariant phi bias) has an analytically ZERO gradient: both sides then hold pure rounding noise, so the error
+    is scaled by the gradient of the companion ``.weight`` instead."""
+    got = params[key].grad.detach().float().cpu()
+    ref = torch.as_tensor(ref).detach().float()
+    scale = float(ref.abs().max())
+    if key.endswith('.bias'):
+        w = ref_of(key[:-5] + '.weight')
+        if w is not None:
+            scale = max(scale, float(torch.as_tensor(w).abs().max()))
+    err = float((got - ref).abs().max())
+    # absolute floor: fp32 rounding noise of sums over ~1e4 O(1) terms (zero-gradient parameters without a companion)
+    return err / max(scale, 1e-6) < tol or err < 2e-5
+
+
+def _head_run(training, dtype):
+    from semseg_amd.lawin import LawinHead
+    from semseg_amd.runtime import set_compute_dtype
+    head = det_fill_(LawinHead(CH, 128, 6)).cuda()
+    head.train(training)
+    head.dropout.p = 0.0
+    feats = [det_input(f'head.f{i}', (2, c, 32 >> i, 32 >> i), -1, 1).cuda().requires_grad_(True) for i, c in enumerate(CH)]
+    set_compute_dtype(dtype)
+    try:
+        out = head(feats)
+        proj = det_input('head.proj', out.shape, -1, 1).cuda()
+        (out.float() * proj).sum().backward()
+    finally:
+        set_compute_dtype(None)
+    return head, feats, out
+
+
+@pytest.mark.parametrize('training', [False, True])
+def test_lawin_head_fp32_matches_reference_golden(golden_dir, training):
+    g = np.load(os.path.join(golden_dir, f"lawin_e128_{'train' if training else 'eval'}.npz"))
+    head, feats, out = _head_run(training, torch.float32)
+    assert rel(out, g['out']) < 1e-4
+    for i in range(4):
+        assert rel(feats[i].grad, g[f'dfeat{i}']) < 3e-4, i
+    params = dict(head.named_parameters())
+    for k in g.files:
+        if k.startswith('grad.'):
+            assert grad_close(params, k[5:], g[k], lambda n: g['grad.' + n] if 'grad.' + n in g.files else None, 3e-4), k
+    if training:
+        sd = head.state_dict()
+        for k in g.files:
+            if k.startswith('after.'):
+                assert rel(sd[k[6:]].float(), g[k].astype(np.float32)) < 1e-4, k
+
+
+def test_lawin_head_bf16_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'lawin_e128_train.npz'))
+    head, feats, out = _head_run(True, torch.bfloat16)
+    assert out.dtype == torch.bfloat16 and rel_l2(out, g['out']) < 2e-2
+
+    def budget(key):
+        # 2e-2 (BASELINE north star), or 1.25 x the deviation of the reference's OWN bf16-autocast run from its fp32 run
+        # where that is larger: through the training-mode BN chain the reference's bf16 gradients sit at 1e-2 .. 9e-2
+        # (bf16.* vectors in the fixture, written by make_golden.py), so no bf16 engine can meet 2e-2 against fp32 there.
+        return max(2e-2, 1.25 * rel_l2(g['bf16.' + key], g[key]))
+
+    for i in range(4):
+        assert rel_l2(feats[i].grad, g[f'dfeat{i}']) < budget(f'dfeat{i}'), i
+    params = dict(head.named_parameters())
+    for k in g.files:
+        if k.startswith('grad.') and float(np.abs(g[k]).max()) > 1e-4:       # skip analytically-zero bias gradients
+            assert rel_l2(params[k[5:]].grad, g[k]) < budget(k), k
+
+
+def test_lawin_head_dropout_mask_and_nonsquare_vs_oracle(monkeypatch):
+    """non-square 192x128 tile (S/8 = 24x16 -> 3x2 windows), E = 256, explicit Dropout2d multiplier."""
+    from oracle import lawin as olawin
+    from semseg_amd.lawin import LawinHead
+    head = det_fill_(LawinHead(CH, 256, 5)).cuda().train()
+    mask = (torch.rand(2, 256, generator=torch.Generator().manual_seed(3)) > 0.2).float() / 0.8
+    monkeypatch.setattr(head, '_drop_mask', lambda b, dt, dev: mask.to(dev))
+    feats_cpu = [det_input(f'h2.f{i}', (2, c, 48 >> i, 32 >> i), -1, 1) for i, c in enumerate(CH)]
+    feats = [f.cuda().requires_grad_(True) for f in feats_cpu]
+    out = head(feats)
+    proj = det_input('h2.proj', out.shape, -1, 1)
+    (out * proj.cuda()).sum().backward()
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
+          for k, v in det_state_dict(shapes.lawin_shapes(CH, 256, 5)).items()}
+    fr = [f.clone().requires_grad_(True) for f in feats_cpu]
+    oout = olawin.lawin_head(sd, fr, training=True, drop_mask=mask)
+    (oout * proj).sum().backward()
+    assert rel(out, oout) < 1e-4
+    for i in range(4):
+        assert rel(feats[i].grad, fr[i].grad) < 3e-4
+    params = dict(head.named_parameters())
+    for k in params:
+        assert grad_close(params, k, sd[k].grad, lambda n: sd[n].grad, 5e-4), k
+
+
+def test_segmentor_logits_loss_grads_match_reference_golden(golden_dir):
+    from semseg_amd.model import SegFormerLawin
+    from semseg_amd.loss import OhemCrossEntropyLoss
+    g = np.load(os.path.join(golden_dir, 'segmentor_b0_e128_128.npz'))
+    net = SegFormerLawin('B0', 128, 6)
+    det_fill_(net.encoder), det_fill_(net.decoder)
+    net = net.cuda().eval()
+    x = det_input('seg.x', (2, 3, 128, 128)).cuda()
+    lab = det_labels('seg.lab', (2, 128, 128), 6, cell=8).cuda()
+    out = net(x)
+    assert out.shape == (2, 6, 128, 128) and net.out_channels == 6
+    assert rel(out, g['logits']) < 1e-4
+    crit = OhemCrossEntropyLoss(0, 0.7, 0.1)
+    loss = crit(out, lab)
+    loss.backward()
+    assert rel(loss, g['loss']) < 1e-4
+    assert rel(net.encoder.block1[0].attn.q.weight.grad, g['grad.enc.block1.0.attn.q.weight']) < 5e-4
+    assert rel(net.encoder.patch_embed1.proj.weight.grad, g['grad.enc.patch_embed1.proj.weight']) < 5e-4
+    assert rel(net.decoder.linear_pred.weight.grad, g['grad.head.linear_pred.weight']) < 5e-4
+    assert rel(net.decoder.lawin_8.theta.weight.grad, g['grad.head.lawin_8.theta.weight']) < 5e-4
+    # bf16: within the 2e-2 budget of the fp32 reference logits (the reference's own bf16 autocast sits at 1.7e-2)
+    from semseg_amd.runtime import set_compute_dtype
+    set_compute_dtype(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            ob = net(x)
+    finally:
+        set_compute_dtype(None)
+    assert ob.dtype == torch.bfloat16 and rel_l2(ob, g['logits']) < 2e-2
