@@ -1,0 +1,288 @@
+"""Headline benchmark: train images/sec of MiT-B2 + Lawin(512) at 1024x1024, bf16, per-GPU batch 16 (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = zero grads -> forward (bf16 activations, fp32 parameters/statistics) -> OhemCrossEntropyLoss(0, 0.7, 0.1) ->
+SegmentationMetrics.update (confusion matrix, as core/igniter.py:104 does every training step) -> backward ->
+bucketed gradient all-reduce (RCCL, N > 1) -> AdaBound step.  Inputs are synthetic UAVPal-shaped tiles resident in HBM.
+Rank 0 prints ONE JSON line; `roofline` describes the kernel family that dominates the step, measured live with HIP events
+on the launch stream in one extra instrumented step; `cpu_baseline` times the CPU oracle (port of the reference path) on
+configs[0] on the host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (no sparsity)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--variant', default='B2')
+    ap.add_argument('--embed', type=int, default=512)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--table', action='store_true', help='print the per-entry-point time table to stderr')
+    return ap.parse_args()
+
+
+def synthetic_batch(batch, size, rank, device):
+    g = torch.Generator().manual_seed(1234 + rank)
+    image = torch.rand(batch, 3, size, size, generator=g)
+    small = torch.randint(0, 6, (batch, size // 32, size // 32), generator=g)
+    label = small.repeat_interleave(32, 1).repeat_interleave(32, 2).contiguous()
+    return image.to(device), label.to(device)
+
+
+# ---------------------------------------------------------------- algorithmic work of each C-ABI entry point
+def _sz(dtype_code):
+    return 4 if dtype_code == 0 else 2
+
+
+def entry_work(name, a):
+    """-> (bound, algorithmic flops or bytes) for one launch, from its argument list (include/semseg_hip.h order)."""
+    if name == 'ss_gemm_nt':
+        return 'mfma', 2.0 * a[8] * a[9] * a[10]
+    if name == 'ss_gemm_tn':
+        return 'mfma', 2.0 * a[7] * a[8] * a[9]
+    if name == 'ss_mit_attn_fwd':
+        B, N, Nk, h, D = a[5:10]
+        return 'mfma', 4.0 * B * h * N * Nk * D
+    if name == 'ss_mit_attn_bwd':
+        B, N, Nk, h, D = a[8:13]
+        return 'mfma', 10.0 * B * h * N * Nk * D
+    if name == 'ss_layernorm_fwd':
+        return 'hbm', 2.0 * a[7] * a[8] * _sz(a[0])
+    if name == 'ss_layernorm_bwd':
+        return 'hbm', 3.0 * a[9] * a[10] * _sz(a[0])
+    if name == 'ss_dwconv3_fwd':
+        return 'hbm', 2.0 * a[5] * a[6] * a[7] * a[8] * _sz(a[0])
+    if name == 'ss_dwconv3_bwd':
+        return 'hbm', 3.0 * a[7] * a[8] * a[9] * a[10] * _sz(a[0])
+    if name == 'ss_bn_stats':
+        return 'hbm', 1.0 * a[3] * a[4] * _sz(a[0])
+    if name == 'ss_bn_apply':
+        return 'hbm', (2.0 + (1.0 if a[6] else 0.0)) * a[12] * a[13] * _sz(a[0])
+    if name == 'ss_bn_bwd':
+        return 'hbm', 5.0 * a[14] * a[15] * _sz(a[0])
+    if name == 'ss_colsum':
+        return 'hbm', 1.0 * a[3] * a[4] * a[5] * _sz(a[0])
+    if name == 'ss_add':
+        return 'hbm', 3.0 * a[4] * _sz(a[0])
+    if name == 'ss_bilinear_fwd':
+        B, hi, wi, ho, wo, C = a[5:11]
+        return 'hbm', 1.0 * B * C * (hi * wi + ho * wo) * _sz(a[0])
+    if name == 'ss_bilinear_bwd':
+        B, hi, wi, ho, wo, C = a[5:11]
+        return 'hbm', 1.0 * B * C * (hi * wi + ho * wo) * _sz(a[0])
+    if name == 'ss_im2col':
+        B, H, W, C, k, s, pad, Kp = a[3:11]
+        ho, wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        return 'hbm', 1.0 * (B * H * W * C + B * ho * wo * Kp) * _sz(a[0])
+    if name == 'ss_col2im':
+        B, H, W, C, k, s, pad = a[3:10]
+        ho, wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        return 'hbm', 1.0 * (B * H * W * C + B * ho * wo * k * k * C) * _sz(a[0])
+    if name in ('ss_ohem_ce_fwd', 'ss_confusion_update'):
+        B, C, H, W = (a[7:11] if name == 'ss_ohem_ce_fwd' else a[8:12])
+        return 'hbm', 1.0 * B * H * W * (C * _sz(a[0]) + 8)
+    if name == 'ss_ohem_ce_bwd':
+        B, C, H, W = a[15:19]
+        return 'hbm', 1.0 * B * H * W * (2 * C * _sz(a[0]) + 8 + 4)
+    if name == 'ss_adabound_step':
+        return 'hbm', 28.0 * a[4]
+    return 'hbm', None
+
+
+def kernel_table(trace):
+    torch.cuda.synchronize()
+    tab = {}
+    for name, args, e0, e1 in trace:
+        ms = e0.elapsed_time(e1)
+        bound, work = entry_work(name, args)
+        t = tab.setdefault(name, {'calls': 0, 'ms': 0.0, 'work': 0.0, 'bound': bound, 'known': True})
+        t['calls'] += 1
+        t['ms'] += ms
+        if work is None:
+            t['known'] = False
+        else:
+            t['work'] += work
+    return tab
+
+
+def roofline_from_table(tab):
+    fam = {}
+    for name, t in tab.items():
+        key = 'gemm' if name.startswith('ss_gemm') else name
+        f = fam.setdefault(key, {'calls': 0, 'ms': 0.0, 'work': 0.0, 'bound': t['bound'], 'known': True})
+        for k in ('calls', 'ms', 'work'):
+            f[k] += t[k]
+        f['known'] = f['known'] and t['known']
+    name, f = max(fam.items(), key=lambda kv: kv[1]['ms'])
+    out = {'kernel': 'gemm_kernel (ss_gemm_nt + ss_gemm_tn)' if name == 'gemm' else name, 'bound': f['bound'],
+           'launches_per_step': f['calls'], 'avg_launch_us': 1e3 * f['ms'] / f['calls'],
+           'step_share': f['ms'] / sum(t['ms'] for t in tab.values())}
+    if f['known'] and f['ms'] > 0:
+        per_s = f['work'] / (f['ms'] * 1e-3)
+        if f['bound'] == 'mfma':
+            out.update(achieved=per_s / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s')
+        else:
+            out.update(achieved=per_s / 1e9, peak=HBM_PEAK_GBS, unit='GB/s')
+        out['frac'] = out['achieved'] / out['peak']
+    else:
+        out.update(achieved=None, peak=None, unit=None, frac=None)
+    out['traffic'] = None
+    return out
+
+
+# ---------------------------------------------------------------- CPU baseline: the oracle (port of the reference path) on configs[0]
+def cpu_baseline():
+    from oracle import lawin as olawin, losses as olosses
+    from semseg_amd.detinit import det_state_dict
+    from semseg_amd import shapes
+    cores = min(os.cpu_count() or 1, 16)                        # the box's CPU share for one GPU
+    torch.set_num_threads(cores)
+    sd_e = det_state_dict(shapes.mit_shapes('B0'))
+    sd_h = det_state_dict(shapes.lawin_shapes([32, 64, 160, 256], 256, 6))
+    for sd in (sd_e, sd_h):
+        for k, v in sd.items():
+            if v.is_floating_point() and 'running' not in k:
+                v.requires_grad_(True)
+    x, lab = synthetic_batch(2, 512, 0, 'cpu')
+    crit = olosses.OhemCE(0, 0.7, 0.1)
+    times = []
+    for i in range(4):
+        t0 = time.time()
+        out = olawin.segmentor(sd_e, sd_h, x, 'B0', training=True)
+        loss = crit(out, lab)
+        loss.backward()
+        for sd in (sd_e, sd_h):
+            for v in sd.values():
+                v.grad = None
+        times.append(time.time() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {'value': 2.0 / t, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': 'configs[0]: MiT-B0 + Lawin(256, 6 cls) fp32, batch 2x3x512x512, fwd + OHEM-CE + bwd, median of 3 steps after 1 warm-up'}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch N > 1 through torch.distributed.run')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    from semseg_amd.model import SegFormerLawin
+    from semseg_amd.loss import OhemCrossEntropyLoss
+    from semseg_amd.metrics import SegmentationMetrics
+    from semseg_amd.detinit import det_fill_
+    from semseg_amd.runtime import set_compute_dtype
+    from semseg_amd.engine import FlatParams, GradReducer, AdaBound, broadcast_module_state
+    from semseg_amd import _lib
+
+    T = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    set_compute_dtype(T)
+    net = SegFormerLawin(a.variant, a.embed, 6)
+    det_fill_(net.encoder), det_fill_(net.decoder)
+    net = net.to(dev).train()
+    broadcast_module_state(net)
+    flat = FlatParams(net)
+    reducer = GradReducer(flat)
+    opt = AdaBound(flat, lr=1e-3, final_lr=0.1)
+    crit = OhemCrossEntropyLoss(0, 0.7, 0.1)
+    met = SegmentationMetrics(6, ignore_index=0).to(dev)
+    x, lab = synthetic_batch(a.batch, a.size, rank, dev)
+
+    def step():
+        flat.zero_grad()
+        out = net(x)
+        loss = crit(out, lab)
+        met.update(out, lab)
+        loss.backward()
+        opt.step(reducer.wait())
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    cm = met.compute()                                           # int64 confusion-matrix all-reduce (C2)
+    roof, table = None, None
+    if not a.no_roofline:                                        # every rank runs the extra step (it contains collectives)
+        _lib.TRACE = []
+        step()
+        trace, _lib.TRACE = _lib.TRACE, None
+        if rank == 0:
+            table = kernel_table(trace)
+            roof = roofline_from_table(table)
+    fence()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms = 1e3 * dt / a.steps
+    res = {'metric': 'train images/sec @1024x1024 (MiT-B2+Lawin)', 'value': a.batch * world * a.steps / dt, 'unit': 'images/s',
+           'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+           'config': {'workload': f'configs[1]: SegFormer MiT-{a.variant} + LawinHead({a.embed}, 6 cls) training step '
+                                  f'(fwd + OHEM-CE + confusion matrix + bwd + grad all-reduce + AdaBound), {a.size}x{a.size}',
+                      'per_gpu_batch': a.batch, 'global_batch': a.batch * world, 'parallelism': f'dp{world}',
+                      'weights': 'deterministic random init'},
+           'loss': float(loss), 'mIoU': float(cm['mIoU']), 'peak_mem_gib': torch.cuda.max_memory_allocated() / 2 ** 30}
+    if roof is not None:
+        res['roofline'] = roof
+    if table is not None and a.table:
+        tot = sum(t['ms'] for t in table.values())
+        for name, t in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
+            rate = ''
+            if t['known'] and t['ms'] > 0:
+                r = t['work'] / (t['ms'] * 1e-3)
+                rate = f"{r / 1e12:8.1f} TFLOP/s" if t['bound'] == 'mfma' else f"{r / 1e9:8.0f} GB/s"
+            print(f"{name:28s} {t['calls']:5d} calls {t['ms']:9.2f} ms {100 * t['ms'] / tot:5.1f}% {rate}", file=sys.stderr)
+        print(f"{'(sum of entry points)':28s} {tot:22.2f} ms", file=sys.stderr)
+    if world == 1 and not a.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -169,6 +169,13 @@ int ss_dice_bwd(int dtype, const int64_t* labels, const float* coef_hit, const f
 int ss_confusion_update(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,
                         int64_t* cm, int B, int C, int H, int W, hipStream_t stream);
 
+/* ---- optimizer step right after the gradient all-reduce: AdaBound as configured in train.py:53-58
+ * (torch_optimizer.AdaBound, absent here: restated from Luo et al. 2019, parity unpinned) over FLAT fp32 buffers -- one launch
+ * for the whole model.  step_size / lower / upper are the per-step scalars of the published algorithm (host computed);
+ * grad_scale multiplies g first (1/world_size when the all-reduce summed). */
+int ss_adabound_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                     float step_size, float lower, float upper, float weight_decay, float grad_scale, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,12 +36,46 @@ def parse_header(path=HEADER):
     return protos
 
 
+TRACE = None            # bench.py sets this to a list to time every entry point with HIP events on the launch stream
+
+
+class _Traced:
+    """Wraps the CDLL so that each ss_* call is bracketed by two HIP events recorded on torch's current stream (the stream
+    every launch of this package uses) and logged as (name, args, start_event, end_event)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        if name.endswith('_workspace') or name in ('ss_last_error', 'ss_version'):
+            return fn
+        import torch
+
+        def call(*args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            TRACE.append((name, args, e0, e1))
+            return rc
+        return call
+
+
 def lib():
+    if TRACE is not None:
+        return _Traced(_load())
+    return _load()
+
+
+def _load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                                '(semseg_amd has no fallback path)')
+        import torch                        # noqa: F401  torch's bundled HIP runtime must be the one already in the process:
+        #                                     loading this library first would pull in /opt/rocm's second copy of libamdhip64
         handle = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in parse_header().items():
             fn = getattr(handle, name, None)
