@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--table', action='store_true', help='print the per-entry-point time table to stderr')
+    ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM / attention timings to stderr')
     return ap.parse_args()
 
 
@@ -125,6 +126,30 @@ def kernel_table(trace):
         else:
             t['work'] += work
     return tab
+
+
+def shape_table(trace):
+    """per-shape timings of the GEMM entry points: TFLOP/s and the HBM rate implied by touching each operand once."""
+    rows = {}
+    for name, a, e0, e1 in trace:
+        if name == 'ss_gemm_nt':
+            M, N, K = a[8:11]
+            sz = _sz(a[0])
+            key = (name, M, N, K, 'res' if a[12] else '', 'f32out' if a[1] else '')
+            byt = (M * K + N * K + M * N * (2 if a[12] else 1)) * sz
+        elif name == 'ss_gemm_tn':
+            M, N, K = a[7:10]
+            key = (name, M, N, K, '', '')
+            byt = (K * M + K * N) * _sz(a[0]) + M * N * 4
+        else:
+            continue
+        r = rows.setdefault(key, [0, 0.0, 2.0 * M * N * K, byt])
+        r[0] += 1
+        r[1] += e0.elapsed_time(e1)
+    for key, (n, ms, fl, byt) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+        per = ms / n
+        print(f"{key[0]:11s} M={key[1]:8d} N={key[2]:5d} K={key[3]:8d} {key[4]:3s} {key[5]:6s} x{n:3d} {ms:8.2f} ms  {per * 1e3:8.1f} us/call "
+              f"{fl / per / 1e9:7.1f} TFLOP/s {byt / per / 1e6:7.0f} GB/s", file=sys.stderr)
 
 
 def roofline_from_table(tab):
@@ -252,6 +277,8 @@ def main():
         if rank == 0:
             table = kernel_table(trace)
             roof = roofline_from_table(table)
+            if a.shapes:
+                shape_table(trace)
     fence()
     if rank != 0:
         if world > 1:

@@ -9,6 +9,7 @@
 // line of tiling code.  Operands are staged global -> registers -> LDS (rows padded by 16 B: conflict-free
 // ds_read_b128), with the next tile's global loads in flight under the current tile's MFMAs.
 #include "common.h"
+#include "gemm_fast.h"
 
 __device__ __forceinline__ floatx16 mma32(bf16x8 a, bf16x8 b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -207,6 +208,32 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit,
     }
 }
 
+// bf16 fast paths (gemm_bf16.hip)
+
+__global__ void reduce_slabs4_kernel(const float* __restrict__ slabs, int nsplit, int zstride, int64_t M, int N, float* __restrict__ out,
+                                     int64_t ldc, int accumulate) {
+    const int64_t n4 = M * N / 4, n = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        floatx4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < nsplit; z += zstride) s += *(const floatx4*)(slabs + (int64_t)z * n + i * 4);
+        int64_t e = i * 4;
+        float* o = out + (e / N) * ldc + (e % N);
+        if (accumulate) s += *(const floatx4*)o;
+        *(floatx4*)o = s;
+    }
+}
+
+// in-place first level of the slab tree: slab[g*group] = sum of slabs g*group .. g*group+group-1 (fixed order)
+__global__ void reduce_slabs_group_kernel(float* __restrict__ slabs, int nsplit, int group, int64_t n4) {
+    const int g = blockIdx.y;
+    const int z0 = g * group, z1 = min(nsplit, z0 + group);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        floatx4 s = *(const floatx4*)(slabs + ((int64_t)z0 * n4 + i) * 4);
+        for (int z = z0 + 1; z < z1; ++z) s += *(const floatx4*)(slabs + ((int64_t)z * n4 + i) * 4);
+        *(floatx4*)(slabs + ((int64_t)z0 * n4 + i) * 4) = s;
+    }
+}
+
 template <typename T, typename TC>
 static int launch_nt(const GemmParams& p, hipStream_t st) {
     dim3 block(256);
@@ -230,6 +257,13 @@ extern "C" int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, co
     SS_CHECK(!res || ldr >= N, "ss_gemm_nt: bad ldr");
     SS_CHECK(!rowscale || rows_per_scale > 0, "ss_gemm_nt: rows_per_scale must be > 0");
     SS_CHECK(cdiv(M, 128) * cdiv(N, 64) < 2147483647LL, "ss_gemm_nt: too many tiles");
+    if (dtype == SS_BF16 && !out_f32 && ss_fast_nt_ok(A, lda, B, ldb, C, ldc, M, N, K, res, ldr, bias)) {
+        FastGemm f{};
+        f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = C; f.M = M; f.N = (int)N; f.K = K; f.lda = lda; f.ldb = ldb; f.ldc = ldc;
+        f.bias = bias; f.res = (const bf16*)res; f.ldr = ldr; f.rowscale = rowscale; f.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+        f.act = act; f.k_per_split = K;
+        return ss_fast_nt_launch(f, stream);
+    }
     GemmParams p{};
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = (int)N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.res = res; p.ldr = ldr; p.rowscale = rowscale; p.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
@@ -243,11 +277,15 @@ extern "C" int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, co
 }
 
 static void tn_plan(int64_t M, int64_t N, int64_t R, int bk, int* nsplit, int64_t* rps) {
+    // split the reduction rows so that ~8 workgroups per CU exist (tail quantisation), every split has >= 4 k-tiles, and the fp32 slabs
+    // (written once, read once) stay below ~a quarter of the operand bytes
     int64_t tiles = cdiv(M, 128) * cdiv(N, N <= 64 ? 64 : 128);
-    int64_t want = cdiv(2048, tiles);                       // ~8 workgroups per CU
-    int64_t maxs = cdiv(R, 4 * bk);                          // at least 4 k-tiles per split
-    int64_t s = want < 1 ? 1 : want;
+    int64_t want = cdiv(2048, tiles);
+    int64_t maxs = cdiv(R, 4 * bk);
+    int64_t cap = (R * (M + N)) / (8 * M * N);
+    int64_t s = want;
     if (s > maxs) s = maxs;
+    if (s > cap) s = cap;
     if (s < 1) s = 1;
     if (s > 1024) s = 1024;
     int64_t per = cdiv(cdiv(R, s), bk) * bk;
@@ -278,7 +316,13 @@ extern "C" int ss_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, 
     p.vecA = aligned16(A) && lda % vec == 0 && M % vec == 0;
     p.vecB = aligned16(B) && ldb % vec == 0 && N % vec == 0;
     dim3 block(256);
-    if (N <= 64) {
+    if (dtype == SS_BF16 && ss_fast_tn_ok(A, lda, B, ldb, M, N)) {
+        FastGemm f{};
+        f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = workspace; f.M = M; f.N = (int)N; f.K = R; f.lda = lda; f.ldb = ldb; f.ldc = N;
+        f.k_per_split = rps;
+        int rc = ss_fast_tn_launch(f, ns, stream);
+        if (rc) return rc;
+    } else if (N <= 64) {
         dim3 grid((unsigned)(cdiv(N, 64) * cdiv(M, 128)), 1, ns);
         if (dtype == SS_F32) hipLaunchKernelGGL((gemm_kernel<float, float, 64, true>), grid, block, 0, stream, p);
         else if (dtype == SS_BF16) hipLaunchKernelGGL((gemm_kernel<bf16, float, 64, true>), grid, block, 0, stream, p);
@@ -291,6 +335,19 @@ extern "C" int ss_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, 
     }
     SS_LAUNCH_CHECK();
     int64_t n = M * N;
+    if (N % 4 == 0 && ldc % 4 == 0 && aligned16(C)) {
+        int64_t n4 = n / 4;
+        int rb4 = (int)(cdiv(n4, 256) < 4096 ? cdiv(n4, 256) : 4096);
+        int zstride = 1;
+        if (ns > 32) {
+            zstride = 32;
+            hipLaunchKernelGGL(reduce_slabs_group_kernel, dim3(rb4, (unsigned)cdiv(ns, 32)), dim3(256), 0, stream, (float*)workspace, ns, 32, n4);
+            SS_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(reduce_slabs4_kernel, dim3(rb4), dim3(256), 0, stream, (const float*)workspace, ns, zstride, M, (int)N, C, ldc, accumulate);
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
     int rb = (int)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rb), dim3(256), 0, stream, (const float*)workspace, ns, M, (int)N, C, ldc, accumulate);
     SS_LAUNCH_CHECK();

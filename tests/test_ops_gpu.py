@@ -52,6 +52,41 @@ def test_gemm_nt(ops, dtype, M, N, K):
     assert out2.dtype == torch.float32 and rel(out2, F.gelu(q(a, dtype) @ q(b, dtype).t())) < (1e-4 if dtype == torch.float32 else 1e-3)
 
 
+@pytest.mark.parametrize('M,N,K', [(1000, 64, 64), (777, 128, 128), (4099, 320, 320), (513, 512, 560), (260, 1280, 320), (300, 48 + 512, 512),
+                                   (2050, 256, 2560), (129, 576, 152), (640, 8, 64)])
+def test_gemm_nt_bf16_fast_path(ops, M, N, K):
+    """shapes that take the 128 x {64,128} x 64 bf16 kernels: ragged M, K tails (K % 64 != 0), N tails, bias + GELU + DropPath row
+    scale + residual in the epilogue, and writes into a channel slice of a wider buffer."""
+    dtype = torch.bfloat16
+    a, b, bias, res = rnd(M, K), rnd(N, K, seed=1) / math.sqrt(K), rnd(N, seed=2), rnd(M, N, seed=3)
+    scale = torch.tensor([1.0, 0.0, 2.0, 0.5])
+    rps = (M + 3) // 4
+    pre = q(a, dtype) @ q(b, dtype).t() + bias
+    ref = pre * scale.repeat_interleave(rps)[:M, None] + q(res, dtype)
+    out = ops.gemm_nt(dev(a, dtype), dev(b, dtype), bias=dev(bias), res=dev(res, dtype), rowscale=dev(scale), rows_per_scale=rps)
+    assert rel(out, ref) < 1e-2
+    wide = torch.full((M, N + 16), 7.0, dtype=dtype, device='cuda')
+    ops.gemm_nt(dev(a, dtype), dev(b, dtype), bias=dev(bias), act=1, out=wide[:, 8:8 + N])
+    assert rel(wide[:, 8:8 + N], F.gelu(pre)) < 1e-2
+    assert float((wide[:, :8] - 7).abs().max()) == 0 and float((wide[:, 8 + N:] - 7).abs().max()) == 0
+    big = dev(rnd(M, K + 24), dtype)                          # strided A (a channel slice of a concat buffer)
+    out3 = ops.gemm_nt(big[:, 8:8 + K], dev(b, dtype))
+    assert rel(out3, big[:, 8:8 + K].float().cpu() @ q(b, dtype).t()) < 1e-2
+
+
+@pytest.mark.parametrize('R,M,N', [(5000, 64, 64), (4097, 320, 1280), (9000, 512, 48 + 512), (1024, 128, 2048), (70, 8, 16), (3000, 1152, 320)])
+def test_gemm_tn_bf16_fast_path(ops, R, M, N):
+    dtype = torch.bfloat16
+    a, b = rnd(R, M), rnd(R, N, seed=1)
+    ref = q(a, dtype).t() @ q(b, dtype)
+    out = ops.gemm_tn(dev(a, dtype), dev(b, dtype))
+    assert rel(out, ref) < 2e-3
+    big_a, big_b = dev(rnd(R, M + 16), dtype), dev(rnd(R, N + 8, seed=5), dtype)     # strided operands
+    out2 = ops.gemm_tn(big_a[:, 8:8 + M], big_b[:, :N])
+    assert rel(out2, big_a[:, 8:8 + M].float().cpu().t() @ big_b[:, :N].float().cpu()) < 2e-3
+    assert torch.equal(out, ops.gemm_tn(dev(a, dtype), dev(b, dtype)))
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_gemm_nt_strided(ops, dtype):
     big_a, b = rnd(200, 96), rnd(40, 32, seed=1)
