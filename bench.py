@@ -141,6 +141,11 @@ def shape_table(trace):
             M, N, K = a[7:10]
             key = (name, M, N, K, '', '')
             byt = (K * M + K * N) * _sz(a[0]) + M * N * 4
+        elif name.startswith(('ss_lawin', 'ss_mit_attn', 'ss_bn_', 'ss_dwconv', 'ss_colsum', 'ss_bilinear')):
+            key = (name, 0, 0, 0, ' '.join(str(v) for v in a[1:] if isinstance(v, int) and 0 <= v < (1 << 22)), '')
+            M = N = K = 0
+            _, w = entry_work(name, a)
+            byt = w or 0
         else:
             continue
         r = rows.setdefault(key, [0, 0.0, 2.0 * M * N * K, byt])
@@ -148,6 +153,9 @@ def shape_table(trace):
         r[1] += e0.elapsed_time(e1)
     for key, (n, ms, fl, byt) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
         per = ms / n
+        if key[1] == 0:
+            print(f"{key[0]:22s} [{key[4]}] x{n:3d} {ms:8.2f} ms {per * 1e3:8.1f} us/call work-rate {byt / per / 1e6:9.0f} M/s", file=sys.stderr)
+            continue
         print(f"{key[0]:11s} M={key[1]:8d} N={key[2]:5d} K={key[3]:8d} {key[4]:3s} {key[5]:6s} x{n:3d} {ms:8.2f} ms  {per * 1e3:8.1f} us/call "
               f"{fl / per / 1e9:7.1f} TFLOP/s {byt / per / 1e6:7.0f} GB/s", file=sys.stderr)
 

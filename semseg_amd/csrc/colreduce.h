@@ -34,8 +34,10 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(F f, int64_t row
         for (int k = 0; k < K; ++k)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
-        if (rl < rpb && chunk < chunks)
+        if (rl < rpb && chunk < chunks) {
+#pragma unroll 4
             for (int64_t r = (int64_t)blockIdx.x * rpb + rl; r < rows; r += (int64_t)nb * rpb) f((int64_t)g * rows + r, chunk * 8, acc);
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             __syncthreads();
@@ -55,23 +57,25 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(F f, int64_t row
     }
 }
 
-// out[g][col] = scale * sum_b partial[g][b][col]   (ncols = K*C).  32 columns x 8 row-parts per block, fixed summation order.
+// out[g][col] = scale * sum_b partial[g][b][col]   (ncols = K*C).  8 columns x 32 row-parts per block: each thread sums
+// nb/32 rows with independent loads, the parts are combined through LDS in a fixed order (bitwise reproducible).
 static __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ partial, int nb, int ncols, float scale,
                                                                    float* __restrict__ out, int accumulate) {
-    __shared__ float sh[8][33];
-    const int cx = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int col = blockIdx.x * 32 + cx, g = blockIdx.y;
+    __shared__ float sh[32][9];
+    const int cx = threadIdx.x & 7, part = threadIdx.x >> 3;
+    const int col = blockIdx.x * 8 + cx, g = blockIdx.y;
     float s = 0.f;
     if (col < ncols) {
         const float* p = partial + (int64_t)g * nb * ncols + col;
-        for (int b = part; b < nb; b += 8) s += p[(int64_t)b * ncols];
+#pragma unroll 4
+        for (int b = part; b < nb; b += 32) s += p[(int64_t)b * ncols];
     }
     sh[part][cx] = s;
     __syncthreads();
     if (part == 0 && col < ncols) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += sh[k][cx];
+        for (int k = 0; k < 32; ++k) t += sh[k][cx];
         float* o = out + (int64_t)g * ncols + col;
         *o = accumulate ? *o + scale * t : scale * t;
     }

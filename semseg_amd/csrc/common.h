@@ -91,16 +91,19 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
-// Mish(x) = x * tanh(softplus(x)), softplus threshold 20 as torch
+// Mish(x) = x * tanh(softplus(x)).  With e = exp(x) and n = e (e + 2):  tanh(log(1 + e)) = n / (n + 2)  (no cancellation),
+// 1 - tanh^2 = 4 (n + 1) / (n + 2)^2, sigmoid = e / (1 + e): one expf and two divisions instead of expf + log1pf + tanhf.
+// x > 20: Mish(x) = x to fp32 precision (torch's softplus threshold); x << 0: e underflows to 0 and both forms return 0.
 __device__ __forceinline__ float mish_f(float x) {
-    float sp = x > 20.f ? x : log1pf(expf(x));
-    return x * tanhf(sp);
+    if (x > 20.f) return x;
+    float e = expf(x), n = e * (e + 2.f);
+    return x * (n / (n + 2.f));
 }
 __device__ __forceinline__ float mish_grad(float x) {
-    float sp = x > 20.f ? x : log1pf(expf(x));
-    float t = tanhf(sp);
-    float sig = 1.f / (1.f + expf(-x));
-    return t + x * (1.f - t * t) * sig;
+    if (x > 20.f) return 1.f;
+    float e = expf(x), n = e * (e + 2.f), d = 1.f / (n + 2.f);
+    float t = n * d, omt2 = 4.f * (n + 1.f) * d * d;
+    return t + x * omt2 * (e / (1.f + e));
 }
 
 // dtype dispatch for extern "C" entry points

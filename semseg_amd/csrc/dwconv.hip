@@ -128,7 +128,7 @@ extern "C" int ss_dwconv3_bwd(int dtype, const void* dy, const void* x, const fl
     SS_DISPATCH(dtype, hipLaunchKernelGGL((dwconv3_bwd_kernel<T>), dim3(geo.nb), dim3(256), 0, stream, (const T*)dy, (const T*)x, w9c, bias,
                                           (T*)g, workspace, B, H, W, C, act, geo.cpb, geo.rpb));
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(10 * C, 32), 1), dim3(256), 0, stream, workspace, geo.nb, 10 * C, 1.f, dw_db, 0);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(10 * C, 8), 1), dim3(256), 0, stream, workspace, geo.nb, 10 * C, 1.f, dw_db, 0);
     SS_LAUNCH_CHECK();
     return 0;
 }

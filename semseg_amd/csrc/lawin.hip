@@ -386,7 +386,7 @@ extern "C" int ss_lawin_mix_wgrad(int dtype, const void* G, const void* dwin, fl
                                           (const T*)dwin, workspace, g, C, heads, (int)wpc));
     SS_LAUNCH_CHECK();
     const int ncols = heads * 64 * 65;
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(ncols, 32), 1), dim3(256), 0, stream, workspace, (int)chunks, ncols, 1.f, dWb, 0);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(ncols, 8), 1), dim3(256), 0, stream, workspace, (int)chunks, ncols, 1.f, dWb, 0);
     SS_LAUNCH_CHECK();
     return 0;
 }

@@ -149,7 +149,7 @@ extern "C" int ss_layernorm_bwd(int dtype, const void* dy, const void* x, const 
         else hipLaunchKernelGGL((layernorm_bwd_kernel<T, 2>), dim3(blocks), dim3(256), shm, stream, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, workspace, rows, C, lpr);
     });
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(2 * C, 32), 1), dim3(256), 0, stream, workspace, blocks, 2 * C, 1.f, dgamma, 0);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(2 * C, 8), 1), dim3(256), 0, stream, workspace, blocks, 2 * C, 1.f, dgamma, 0);
     SS_LAUNCH_CHECK();
     return 0;
 }
@@ -176,31 +176,45 @@ extern "C" int ss_colsum(int dtype, const void* x, int64_t ld, int64_t rows, int
         hipLaunchKernelGGL((colreduce_partial_kernel<ColSumF<T>>), dim3(g.nb, groups), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
     });
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(C, 32), groups), dim3(256), 0, stream, workspace, g.nb, C, scale, out, accumulate);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(C, 8), groups), dim3(256), 0, stream, workspace, g.nb, C, scale, out, accumulate);
     SS_LAUNCH_CHECK();
     return 0;
 }
 
 // ------------------------------------------------------------------ BatchNorm2d on [rows, C]
+// Shifted sums: d = x - x[row 0] per channel, so that var = E[d^2] - E[d]^2 does not cancel when |mean| >> std
+// (sum x^2 - n mean^2 in fp32 loses the variance of a channel whose values nearly agree, e.g. the (B,C,1,1) image-pool BN).
 template <typename T> struct BnStatF {
     static constexpr int K = 2;
     const T* x; int64_t ld;
     __device__ void operator()(int64_t row, int c0, float (&acc)[2][8]) const {
-        F8 v = load8(x + row * ld + c0);
+        F8 v = load8(x + row * ld + c0), s = load8(x + c0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { acc[0][e] += v.v[e]; acc[1][e] += v.v[e] * v.v[e]; }
+        for (int e = 0; e < 8; ++e) { float d = v.v[e] - s.v[e]; acc[0][e] += d; acc[1][e] += d * d; }
     }
 };
 
 // stats[0][c] = mean, stats[1][c] = rstd (biased variance); running stats updated like nn.BatchNorm2d (unbiased var)
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nb, int C, int64_t n, float eps, float momentum,
-                                   float* __restrict__ stats, float* running_mean, float* running_var, int64_t* nbt) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
+// 8 channels x 32 row-parts per block (double accumulation, fixed order)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nb, int C, int64_t n, float eps, float momentum,
+                                   float* __restrict__ stats, float* running_mean, float* running_var, int64_t* nbt,
+                                   const void* __restrict__ x, int x_is_bf16) {
+    __shared__ double sh[2][32][9];
+    const int cx = threadIdx.x & 7, part = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cx;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nb; ++b) { s += partial[((int64_t)b * 2 + 0) * C + c]; q += partial[((int64_t)b * 2 + 1) * C + c]; }
-    double mu = s / (double)n, var = q / (double)n - mu * mu;
+    if (c < C) {
+#pragma unroll 4
+        for (int b = part; b < nb; b += 32) { s += partial[((int64_t)b * 2 + 0) * C + c]; q += partial[((int64_t)b * 2 + 1) * C + c]; }
+    }
+    sh[0][part][cx] = s; sh[1][part][cx] = q;
+    __syncthreads();
+    if (part != 0 || c >= C) return;
+    s = 0.0; q = 0.0;
+    for (int k = 0; k < 32; ++k) { s += sh[0][k][cx]; q += sh[1][k][cx]; }
+    const double shift = x_is_bf16 ? (double)(float)((const bf16*)x)[c] : (double)((const float*)x)[c];
+    double md = s / (double)n, var = q / (double)n - md * md, mu = shift + md;
     if (var < 0) var = 0;
     stats[c] = (float)mu;
     stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -222,8 +236,8 @@ extern "C" int ss_bn_stats(int dtype, const void* x, int64_t ld, int64_t rows, i
         hipLaunchKernelGGL((colreduce_partial_kernel<BnStatF<T>>), dim3(g.nb, 1), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
     });
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, workspace, g.nb, C, rows, eps, momentum,
-                       stats, running_mean, running_var, num_batches_tracked);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, g.nb, C, rows, eps, momentum,
+                       stats, running_mean, running_var, num_batches_tracked, x, dtype == SS_BF16 ? 1 : 0);
     SS_LAUNCH_CHECK();
     return 0;
 }
@@ -300,12 +314,21 @@ template <typename T> struct BnBwdF {
 };
 
 // dgb[0][c] = dgamma = sum g*xhat ; dgb[1][c] = dbeta = sum g ; coef[0][c] = mean g, coef[1][c] = mean g*xhat (0 in eval mode)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int C, int64_t n, int training,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int C, int64_t n, int training,
                                        float* __restrict__ dgb, float* __restrict__ coef) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sh[2][32][9];
+    const int cx = threadIdx.x & 7, part = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cx;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nb; ++b) { s += partial[((int64_t)b * 2 + 0) * C + c]; q += partial[((int64_t)b * 2 + 1) * C + c]; }
+    if (c < C) {
+#pragma unroll 4
+        for (int b = part; b < nb; b += 32) { s += partial[((int64_t)b * 2 + 0) * C + c]; q += partial[((int64_t)b * 2 + 1) * C + c]; }
+    }
+    sh[0][part][cx] = s; sh[1][part][cx] = q;
+    __syncthreads();
+    if (part != 0 || c >= C) return;
+    s = 0.0; q = 0.0;
+    for (int k = 0; k < 32; ++k) { s += sh[0][k][cx]; q += sh[1][k][cx]; }
     dgb[c] = (float)q; dgb[C + c] = (float)s;
     coef[c] = training ? (float)(s / (double)n) : 0.f;
     coef[C + c] = training ? (float)(q / (double)n) : 0.f;
@@ -350,7 +373,7 @@ extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, 
         BnBwdF<T> f{(const T*)dy, ldd, (const T*)z, ldz, stats, gamma, beta, mask, rows_per_image, C, act};
         hipLaunchKernelGGL((colreduce_partial_kernel<BnBwdF<T>>), dim3(g.nb, 1), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, workspace, g.nb, C, rows, training, dgamma_dbeta, coef);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, g.nb, C, rows, training, dgamma_dbeta, coef);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL((bn_bwd_dz_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)dy, ldd, (const T*)z, ldz, stats, gamma, beta,
                            mask, rows_per_image, coef, (T*)dz, ldo, rows, C, act);
@@ -384,7 +407,7 @@ extern "C" int ss_colsum_small(int dtype, const void* x, int64_t ld, int64_t row
     SS_CHECK(ws_bytes >= (int64_t)nb * C * 4, "ss_colsum_small: workspace too small");
     SS_DISPATCH(dtype, hipLaunchKernelGGL((colsum_small_kernel<T>), dim3(nb), dim3(256), 0, stream, (const T*)x, ld, rows, C, workspace));
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(C, 32), 1), dim3(256), 0, stream, workspace, nb, C, 1.f, out, 0);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(C, 8), 1), dim3(256), 0, stream, workspace, nb, C, 1.f, out, 0);
     SS_LAUNCH_CHECK();
     return 0;
 }

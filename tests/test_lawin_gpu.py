@@ -36,7 +36,10 @@ def grad_close(params, key, ref, ref_of, tol):
             scale = max(scale, float(torch.as_tensor(w).abs().max()))
     err = float((got - ref).abs().max())
     # absolute floor: fp32 rounding noise of sums over ~1e4 O(1) terms (zero-gradient parameters without a companion)
-    return err / max(scale, 1e-6) < tol or err < 2e-5
+    ok = err / max(scale, 1e-6) < tol or err < 2e-5
+    if not ok:
+        print(f'grad_close({key}): max abs err {err:.3e}, scale {scale:.3e}, ratio {err / max(scale, 1e-6):.3e} >= {tol}')
+    return ok
 
 
 def _head_run(training, dtype):
