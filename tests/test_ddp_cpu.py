@@ -1,0 +1,96 @@
+"""World-size-2 checks (gloo, CPU processes) of the two exchange steps of the data-parallel path:
+C1 bucketed gradient all-reduce over the flat gradient buffer, C2 the int64 confusion-matrix sum."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(7)
+    return torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.GELU(), torch.nn.Linear(40, 33), torch.nn.GELU(), torch.nn.Linear(33, 5))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from semseg_amd.engine import FlatParams, GradReducer, broadcast_module_state
+    from semseg_amd.metrics import SegmentationMetrics
+    from oracle import metrics as ometrics
+    net = _model()
+    if rank == 1:                                   # DDP start-up: rank 0's parameters win
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    broadcast_module_state(net)
+    flat = FlatParams(net)
+    red = GradReducer(flat, bucket_bytes=1024)      # several buckets, launched from the grad hooks during backward
+    assert len(red.buckets) >= 3
+    g = torch.Generator().manual_seed(100)
+    xs, ys = torch.randn(8, 24, generator=g), torch.randn(8, 5, generator=g)
+    res = {}
+    for step in range(2):                           # two steps: the reducer re-arms itself
+        flat.zero_grad()
+        lo = rank * 4
+        loss = ((net(xs[lo:lo + 4]) - ys[lo:lo + 4]) ** 2).mean()
+        loss.backward()
+        scale = red.wait()
+        res[f'grad{step}'] = (flat.grad * scale).clone()
+    res['param_views_ok'] = all(p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
+    # C2: every rank adds its own tiles' counts; the int64 all-reduce makes every rank see the union
+    met = SegmentationMetrics(4, ignore_index=0)
+    gg = torch.Generator().manual_seed(5 + rank)
+    logits, target = torch.randn(2, 4, 8, 8, generator=gg), torch.randint(0, 4, (2, 8, 8), generator=gg)
+    met.confmat += ometrics.confusion_matrix(logits, target, 4)
+    res['cm'] = met.compute()['Confusion_Matrix'].clone()
+    res['miou'] = met.compute()['mIoU'].clone()
+    torch.save(res, os.path.join(out, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_bucketed_grad_allreduce_and_confmat_sum_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'r{r}.pt'), weights_only=True) for r in (0, 1))
+    # single-process reference: mean over the global batch == mean over ranks of per-rank means (equal shards)
+    sys.path.insert(0, ROOT)
+    from oracle import metrics as ometrics
+    net = _model()
+    g = torch.Generator().manual_seed(100)
+    xs, ys = torch.randn(8, 24, generator=g), torch.randn(8, 5, generator=g)
+    ((net(xs) - ys) ** 2).mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in reversed(list(net.parameters()))])
+    for r in (r0, r1):
+        assert r['param_views_ok']
+        for step in range(2):
+            got = torch.cat([r[f'grad{step}'][o:o + n] for o, n in _layout(net)])
+            assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
+    assert torch.equal(r0['grad0'], r1['grad0']) and torch.equal(r0['cm'], r1['cm']) and torch.equal(r0['miou'], r1['miou'])
+    cms = []
+    for rank in (0, 1):
+        gg = torch.Generator().manual_seed(5 + rank)
+        logits, target = torch.randn(2, 4, 8, 8, generator=gg), torch.randint(0, 4, (2, 8, 8), generator=gg)
+        cms.append(ometrics.confusion_matrix(logits, target, 4))
+    assert torch.equal(r0['cm'], cms[0] + cms[1]) and r0['cm'].dtype == torch.int64
+
+
+def _layout(net, align=64):
+    offs, n = [], 0
+    for p in reversed(list(net.parameters())):
+        offs.append((n, p.numel()))
+        n += (p.numel() + align - 1) // align * align
+    return offs
