@@ -15,32 +15,7 @@
 // Backward = two kernels (deterministic, no atomics): dQ (lane = query, loops keys) and dK/dV (lane = key, loops a
 // slice of the queries, fp32 partial slabs summed by attn_bwd_finish_kernel).  P is recomputed from the forward LSE.
 #include "common.h"
-
-__device__ __forceinline__ floatx16 mma32(bf16x8 a, bf16x8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ floatx16 mma32(floatx8 a, floatx8 b, floatx16 c) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
-    return c;
-}
-template <typename T> struct AT;
-template <> struct AT<bf16> { typedef bf16x8 frag; };
-template <> struct AT<float> { typedef floatx8 frag; };
-
-__device__ __forceinline__ bf16x8 ldg_frag(const bf16* p) { return *(const bf16x8*)p; }
-__device__ __forceinline__ floatx8 ldg_frag(const float* p) {
-    floatx4 a = *(const floatx4*)p, b = *(const floatx4*)(p + 4); floatx8 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { r[i] = a[i]; r[4 + i] = b[i]; }
-    return r;
-}
-template <typename T> __device__ __forceinline__ typename AT<T>::frag cvt_frag(const floatx16& s, int st) {
-    typename AT<T>::frag f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = (T)s[8 * st + e];
-    return f;
-}
-__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-__device__ __forceinline__ int perm16(int pos) { return 8 * ((pos & 7) >> 2) + 4 * (pos >> 3) + (pos & 3); }
+#include "attn_common.h"
 
 // ------------------------------------------------------------------ operand preparation
 // Xt[b][hd][dd][pos] = X[b][16*(pos>>4) + perm16(pos&15)][off + hd*D + dd]   (zero for rows >= n);  np = n rounded up to 32
@@ -81,27 +56,6 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(const T* __restrict__ 
         s = group_sum(s, gl);
         if (ok && (ch % gl) == 0) { int64_t b = row / n; int q = (int)(row % n), hd = ch / gl; delta[(b * heads + hd) * np + q] = s; }
     }
-}
-
-// LDS transpose of a lane-major accumulator (acc[t][r] = X^T[dd = acc_row(r,h)+32t][col = lane&31]) into row-major
-// dst[(row0 + col)*ld + dd], rows < nrows.   `sh` = this wave's 32*(D+1) floats.
-template <typename TO, int D>
-__device__ __forceinline__ void store_transposed(const floatx16 (&acc)[D / 32], float mul, float* sh, TO* dst, int64_t ld, int nrows) {
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < D / 32; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sh[j * (D + 1) + t * 32 + acc_row(r, h)] = acc[t][r] * mul;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 32 * (D / 8) / 64; ++it) {
-        int c = lane + it * 64, row = c / (D / 8), cc = c % (D / 8);
-        F8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v.v[e] = sh[row * (D + 1) + cc * 8 + e];
-        if (row < nrows) store8(dst + (int64_t)row * ld + cc * 8, v);
-    }
-    __builtin_amdgcn_wave_barrier();
 }
 
 // ------------------------------------------------------------------ forward
@@ -317,6 +271,12 @@ extern "C" int ss_mit_attn_fwd(int dtype, const void* q, const void* kv, void* o
     SS_CHECK(aligned16(q) && aligned16(kv) && aligned16(o) && aligned16(workspace), "ss_mit_attn_fwd: pointers must be 16-byte aligned");
     const int Np = round32(N), Nkp = round32(Nk);
     const float c = scale * 1.4426950408889634f;
+    if (dtype == SS_BF16) {
+        AttnBf16Args a{};
+        a.q = (const bf16*)q; a.kv = (const bf16*)kv; a.out = (bf16*)o; a.lse_out = lse;
+        a.B = B; a.N = N; a.Np = Np; a.Nk = Nk; a.Nkp = Nkp; a.heads = heads; a.D = D; a.C = C; a.c = c; a.scale = scale;
+        return attn_fwd_bf16_launch(a, stream);
+    }
     SS_DISPATCH(dtype, {
         dim3 tg((unsigned)cdiv(Nkp, 64), heads, B), g((unsigned)cdiv(cdiv(N, 32), 4), heads, B);
         if (D == 64) {
@@ -397,6 +357,23 @@ extern "C" int ss_mit_attn_bwd(int dtype, const void* q, const void* kv, const v
     float* dvs = (float*)w;
     const float c = scale * 1.4426950408889634f;
     SS_HIP(hipMemsetAsync(delta, 0, (int64_t)B * heads * Np * 4, stream));
+    if (dtype == SS_BF16) {
+        const int64_t rows = (int64_t)B * N;
+        int rb = (int)(cdiv(rows * (C / 8), 256) < 8192 ? cdiv(rows * (C / 8), 256) : 8192);
+        hipLaunchKernelGGL((attn_rowdot_kernel<bf16>), dim3(rb), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)o, delta, rows, N, Np, C, D, heads);
+        SS_LAUNCH_CHECK();
+        AttnBf16Args f{};
+        f.q = (const bf16*)q; f.kv = (const bf16*)kv; f.o = (const bf16*)o; f.dout = (const bf16*)dout; f.lse = lse; f.dq = (bf16*)dq;
+        f.dkv = (bf16*)dkv; f.delta = delta; f.dks = dks; f.dvs = dvs;
+        f.B = B; f.N = N; f.Np = Np; f.Nk = Nk; f.Nkp = Nkp; f.heads = heads; f.D = D; f.C = C; f.c = c; f.scale = scale; f.ns = ns; f.qps = qps;
+        int rc = attn_bwd_bf16_launch(f, stream);
+        if (rc) return rc;
+        int64_t tot = (int64_t)B * Nk * 2 * C;
+        int fb = (int)(cdiv(tot, 256) < 4096 ? cdiv(tot, 256) : 4096);
+        hipLaunchKernelGGL((attn_bwd_finish_kernel<bf16>), dim3(fb), dim3(256), 0, stream, dks, dvs, (bf16*)dkv, (int64_t)2 * C, B, Nk, Nkp, heads, D, C, ns);
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
     BwdArgs a{q, kv, o, dout, lse, dq, dkv, delta, ktp, qtp, dotp, dks, dvs, B, N, Np, Nk, Nkp, heads, C, c, scale, ns, qps};
     SS_DISPATCH(dtype, { if (D == 64) attn_bwd_launch<T, 64>(a, stream); else attn_bwd_launch<T, 32>(a, stream); });
     SS_LAUNCH_CHECK();

@@ -1,0 +1,387 @@
+// MiT efficient self-attention, bf16 fast path (reference modules/segformer.py:32-39).
+//
+// Same mathematics and the same "transposed" MFMA formulation as attention.hip (softmax axis lane-local, accumulator of the
+// first product reused as the B operand of the second), but the operands that every wave of a workgroup needs are staged ONCE
+// per workgroup through LDS as 64-row tiles (coalesced 16-byte loads, next tile in flight under the current tile's MFMAs)
+// instead of being fetched per wave, fragment-shaped, from L2:
+//   * row operands (K for S = K.Q^T, V for dP = V.dO^T, Q / dO in the dK/dV kernel) live in a swizzled image read with
+//     ds_read_b128: 16-byte chunk c of row r -> slot ((r % RPB)*CH + c) ^ (R & 15) of bank row R = r / RPB (conflict-free);
+//   * transposed operands (V^T for O^T += V^T.P^T, K^T for dQ, dO^T / Q^T for dV / dK) are read from a plain row-major image
+//     with ds_read_b64_tr_b16, each lane naming the rows of the accumulator's permuted k order
+//     (element e of lane-half h <-> row 16s + 8(e>>2) + 4h + (e&3)), so no pre-transposed copies exist in HBM.
+//     Row pitch 192 B (D = 64) / 64 B (D = 32): the four rows of a transpose block tile the 64 banks.
+// Workgroup = 4 waves x 32 queries (forward, dQ) or 4 x 32 keys (dK/dV); key / query tiles of 64 rows.
+#include "attn_common.h"
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+template <int CH> __device__ __forceinline__ int img_slot(int row, int chunk) {
+    constexpr int RPB = 16 / CH;
+    const int R = row / RPB;
+    return R * 16 + ((((row % RPB) * CH) + chunk) ^ (R & 15));
+}
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int slot) { return *(const bf16x8*)(img + slot * 16); }
+
+// A operand X^T[col][row-perm] of a row-major [row][col] image: lane (li = col within the 32-wide tile, lh) gets rows
+// base + 8(e>>2) + 4 lh + (e&3), e = 0..7.
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int pitch, int base, int col0) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3, gsel = (lane >> 4) & 1, lh = lane >> 5;
+    const char* a0 = img + (base + 4 * lh + tq) * pitch + (col0 + gsel * 16 + 4 * tp) * 2;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 8 * pitch));
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+    return f;
+}
+
+// lane-major accumulator (lane = row j of the output, registers = columns) -> bf16 rows through a per-wave LDS image
+template <int D>
+__device__ __forceinline__ void store_rows_bf16(const floatx16 (&acc)[D / 32], float mul, char* img, bf16* dst, int64_t ld, int nrows) {
+    constexpr int EP = D * 2 + 16, CH = D / 8;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16)(acc[t][4 * g + e] * mul);
+            *(bf16x4*)(img + j * EP + (t * 32 + 8 * g + 4 * h) * 2) = v;
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < CH / 2; ++it) {
+        const int c = lane + it * 64, row = c / CH, cc = c % CH;
+        if (row < nrows) *(bf16x8*)(dst + (int64_t)row * ld + cc * 8) = *(const bf16x8*)(img + row * EP + cc * 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int D> struct AttnCfg {
+    static constexpr int CH = D / 8;                    // 16-byte chunks per row
+    static constexpr int NCH = (64 * CH) / 256;         // chunks per thread per 64-row tile
+    static constexpr int PT = D == 64 ? 192 : 64;       // pitch of the transpose-read image
+    static constexpr int SW = 64 * D * 2;               // bytes of a swizzled image
+    static constexpr int TR = 64 * PT;                  // bytes of a transpose-read image
+    static constexpr int EPI = 4 * 32 * (D * 2 + 16);   // bf16 row-store images of the 4 waves
+    static constexpr int EPF = 4 * 32 * (D + 1) * 4;    // fp32 transposes of the 4 waves
+};
+
+// ------------------------------------------------------------------ forward
+template <int D>
+__global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kv,
+        bf16* __restrict__ o, float* __restrict__ lse, int N, int Np, int Nk, int heads, int C, float c) {
+    typedef AttnCfg<D> G;
+    constexpr int CH = G::CH, NCH = G::NCH, PT = G::PT;
+    constexpr int SMEM = (G::SW + G::TR) > G::EPI ? (G::SW + G::TR) : G::EPI;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    char* Ks = smem; char* Vt = smem + G::SW;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int qrow = min(q0 + j, N - 1);
+    const bf16* qp = q + ((int64_t)b * N + qrow) * C + hd * D;
+    bf16x8 qf[D / 16];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s + 8 * h);
+    const bf16* kbase = kv + (int64_t)b * Nk * 2 * C + hd * D;
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 rk[NCH], rv[NCH];
+    auto gload = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int cidx = tid + i * 256, row = cidx / CH, ch = cidx % CH;
+            const bool ok = key0 + row < Nk;
+            const bf16* src = kbase + (int64_t)(key0 + row) * 2 * C + ch * 8;
+            rk[i] = ok ? *(const bf16x8*)src : zero;
+            rv[i] = ok ? *(const bf16x8*)(src + C) : zero;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int cidx = tid + i * 256, row = cidx / CH, ch = cidx % CH;
+            *(bf16x8*)(Ks + img_slot<CH>(row, ch) * 16) = rk[i];
+            *(bf16x8*)(Vt + row * PT + ch * 16) = rv[i];
+        }
+    };
+    floatx16 oacc[D / 32];
+#pragma unroll
+    for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int key0 = 0; key0 < Nk; key0 += 64) {
+        const bool more = key0 + 64 < Nk;
+        if (more) gload(key0 + 64);
+        floatx16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks)
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, img_slot<CH>(kt * 32 + j, ks * 2 + h)), qf[ks], s[kt], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (key0 + kt * 32 + acc_row(r, h) < Nk) ? s[kt][r] * c : -INFINITY;
+                s[kt][r] = v; mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx), alpha = exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { float p = exp2f(s[kt][r] - mn); s[kt][r] = p; ps += p; }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 pf = cvt_frag<bf16>(s[kt], st);
+#pragma unroll
+                for (int t = 0; t < D / 32; ++t)
+                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, PT, kt * 32 + 16 * st, t * 32), pf, oacc[t], 0, 0, 0);
+            }
+        __syncthreads();
+        if (more) { lstore(); __syncthreads(); }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (h == 0 && q0 + j < N) lse[(int64_t)(b * heads + hd) * Np + q0 + j] = m + log2f(l);
+    if (q0 < N)
+        store_rows_bf16<D>(oacc, 1.f / l, smem + wave * 32 * (D * 2 + 16), o + ((int64_t)b * N + q0) * C + hd * D, C, N - q0);
+}
+
+// ------------------------------------------------------------------ backward: dQ (lane = query)
+template <int D>
+__global__ __launch_bounds__(256, 2) void mit_attn_bwd_dq_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kv,
+        const bf16* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta, bf16* __restrict__ dq,
+        int N, int Np, int Nk, int heads, int C, float c, float scale) {
+    typedef AttnCfg<D> G;
+    constexpr int CH = G::CH, NCH = G::NCH, PT = G::PT;
+    constexpr int STG = 2 * G::SW + G::TR;
+    constexpr int SMEM = STG > G::EPI ? STG : G::EPI;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    char* Ks = smem; char* Vs = smem + G::SW; char* Kt = smem + 2 * G::SW;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int qrow = min(q0 + j, N - 1);
+    bf16x8 qf[D / 16], dof[D / 16];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) {
+        qf[s] = *(const bf16x8*)(q + ((int64_t)b * N + qrow) * C + hd * D + 16 * s + 8 * h);
+        dof[s] = *(const bf16x8*)(dout + ((int64_t)b * N + qrow) * C + hd * D + 16 * s + 8 * h);
+    }
+    const float ls = lse[(int64_t)(b * heads + hd) * Np + qrow], dl = delta[(int64_t)(b * heads + hd) * Np + qrow];
+    const bf16* kbase = kv + (int64_t)b * Nk * 2 * C + hd * D;
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 rk[NCH], rv[NCH];
+    auto gload = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int cidx = tid + i * 256, row = cidx / CH, ch = cidx % CH;
+            const bool ok = key0 + row < Nk;
+            const bf16* src = kbase + (int64_t)(key0 + row) * 2 * C + ch * 8;
+            rk[i] = ok ? *(const bf16x8*)src : zero;
+            rv[i] = ok ? *(const bf16x8*)(src + C) : zero;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int cidx = tid + i * 256, row = cidx / CH, ch = cidx % CH;
+            const int sl = img_slot<CH>(row, ch);
+            *(bf16x8*)(Ks + sl * 16) = rk[i];
+            *(bf16x8*)(Vs + sl * 16) = rv[i];
+            *(bf16x8*)(Kt + row * PT + ch * 16) = rk[i];
+        }
+    };
+    floatx16 acc[D / 32];
+#pragma unroll
+    for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int key0 = 0; key0 < Nk; key0 += 64) {
+        const bool more = key0 + 64 < Nk;
+        if (more) gload(key0 + 64);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            floatx16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) {
+                const int sl = img_slot<CH>(kt * 32 + j, ks * 2 + h);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, sl), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, sl), dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = (key0 + kt * 32 + acc_row(r, h) < Nk) ? exp2f(s[r] * c - ls) : 0.f;
+                s[r] = p * (dp[r] - dl) * scale;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 df = cvt_frag<bf16>(s, st);
+#pragma unroll
+                for (int t = 0; t < D / 32; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, PT, kt * 32 + 16 * st, t * 32), df, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) { lstore(); __syncthreads(); }
+    }
+    if (q0 < N)
+        store_rows_bf16<D>(acc, 1.f, smem + wave * 32 * (D * 2 + 16), dq + ((int64_t)b * N + q0) * C + hd * D, C, N - q0);
+}
+
+// ------------------------------------------------------------------ backward: dK, dV (lane = key); fp32 slabs per query split
+template <int D>
+__global__ __launch_bounds__(256, 2) void mit_attn_bwd_dkv_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ dout,
+        const bf16* __restrict__ kv, const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dk_slab,
+        float* __restrict__ dv_slab, int B, int N, int Np, int Nk, int Nkp, int heads, int C, float c, float scale, int nsplit,
+        int q_per_split) {
+    typedef AttnCfg<D> G;
+    constexpr int CH = G::CH, NCH = G::NCH, PT = G::PT;
+    constexpr int STG = 2 * G::SW + 2 * G::TR + 512;
+    constexpr int SMEM = STG > G::EPF ? STG : G::EPF;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    char* Qs = smem; char* Os = smem + G::SW; char* Qt = smem + 2 * G::SW; char* Ot = Qt + G::TR;
+    float* lsd = (float*)(Ot + G::TR);                   // lse[64] | delta[64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z / nsplit, split = blockIdx.z % nsplit, hd = blockIdx.y;
+    const int key0 = (blockIdx.x * 4 + wave) * 32;
+    const int krow = min(key0 + j, Nk - 1);
+    const bool kvalid = key0 + j < Nk;
+    const bf16* kp = kv + ((int64_t)b * Nk + krow) * 2 * C + hd * D;
+    bf16x8 kf[D / 16], vf[D / 16];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) { kf[s] = *(const bf16x8*)(kp + 16 * s + 8 * h); vf[s] = *(const bf16x8*)(kp + C + 16 * s + 8 * h); }
+    const float* lsep = lse + (int64_t)(b * heads + hd) * Np;
+    const float* dlp = delta + (int64_t)(b * heads + hd) * Np;
+    const bf16* qbase = q + (int64_t)b * N * C + hd * D;
+    const bf16* obase = dout + (int64_t)b * N * C + hd * D;
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 rq[NCH], ro[NCH];
+    float rl = 0.f;
+    auto gload = [&](int q0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int cidx = tid + i * 256, row = cidx / CH, ch = cidx % CH;
+            const bool ok = q0 + row < N;
+            const int64_t off = (int64_t)(q0 + row) * C + ch * 8;
+            rq[i] = ok ? *(const bf16x8*)(qbase + off) : zero;
+            ro[i] = ok ? *(const bf16x8*)(obase + off) : zero;
+        }
+        if (tid < 128) { const int qq = q0 + (tid & 63); rl = qq < N ? (tid < 64 ? lsep[qq] : dlp[qq]) : 0.f; }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int cidx = tid + i * 256, row = cidx / CH, ch = cidx % CH;
+            const int sl = img_slot<CH>(row, ch);
+            *(bf16x8*)(Qs + sl * 16) = rq[i];
+            *(bf16x8*)(Os + sl * 16) = ro[i];
+            *(bf16x8*)(Qt + row * PT + ch * 16) = rq[i];
+            *(bf16x8*)(Ot + row * PT + ch * 16) = ro[i];
+        }
+        if (tid < 128) lsd[tid] = rl;
+    };
+    floatx16 dk[D / 32], dv[D / 32];
+#pragma unroll
+    for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
+    const int qbeg = split * q_per_split, qend = min(N, qbeg + q_per_split);
+    if (qbeg < qend) {
+        gload(qbeg);
+        lstore();
+        __syncthreads();
+        for (int q0 = qbeg; q0 < qend; q0 += 64) {
+            const bool more = q0 + 64 < qend;
+            if (more) gload(q0 + 64);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                floatx16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < D / 16; ++ks) {
+                    const int sl = img_slot<CH>(qt * 32 + j, ks * 2 + h);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qs, sl), kf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Os, sl), vf[ks], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ql = qt * 32 + 8 * g + 4 * h;
+                    const floatx4 l4 = *(const floatx4*)(lsd + ql), d4 = *(const floatx4*)(lsd + 64 + ql);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const bool ok = kvalid && (q0 + ql + e < qend);        // qend <= N; rows past the split belong to the next slab
+                        const float p = ok ? exp2f(s[r] * c - l4[e]) : 0.f;
+                        s[r] = p;
+                        dp[r] = p * (dp[r] - d4[e]) * scale;
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 pf = cvt_frag<bf16>(s, st), df = cvt_frag<bf16>(dp, st);
+#pragma unroll
+                    for (int t = 0; t < D / 32; ++t) {
+                        dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, PT, qt * 32 + 16 * st, t * 32), pf, dv[t], 0, 0, 0);
+                        dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, PT, qt * 32 + 16 * st, t * 32), df, dk[t], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+            if (more) { lstore(); __syncthreads(); }
+        }
+    }
+    if (key0 >= Nkp) return;                              // (after every block-wide barrier)
+    const int64_t slab = (((int64_t)split * B + b) * heads + hd) * Nkp + key0;
+    float* shf = (float*)smem + wave * 32 * (D + 1);
+    store_transposed<float, D>(dk, 1.f, shf, dk_slab + slab * D, D, 32);
+    store_transposed<float, D>(dv, 1.f, shf, dv_slab + slab * D, D, 32);
+}
+
+// ------------------------------------------------------------------ host side
+template <int D> static void fwd_launch(const AttnBf16Args& a, hipStream_t st) {
+    dim3 g((unsigned)cdiv(a.N, 128), a.heads, a.B);
+    hipLaunchKernelGGL((mit_attn_fwd_bf16_kernel<D>), g, dim3(256), 0, st, a.q, a.kv, a.out, a.lse_out, a.N, a.Np, a.Nk, a.heads, a.C, a.c);
+}
+int attn_fwd_bf16_launch(const AttnBf16Args& a, hipStream_t stream) {
+    if (a.D == 64) fwd_launch<64>(a, stream); else fwd_launch<32>(a, stream);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+template <int D> static void bwd_launch(const AttnBf16Args& a, hipStream_t st) {
+    dim3 gq((unsigned)cdiv(a.N, 128), a.heads, a.B), gk((unsigned)cdiv(a.Nkp, 128), a.heads, a.B * a.ns);
+    hipLaunchKernelGGL((mit_attn_bwd_dq_bf16_kernel<D>), gq, dim3(256), 0, st, a.q, a.kv, a.dout, a.lse, a.delta, a.dq, a.N, a.Np, a.Nk,
+                       a.heads, a.C, a.c, a.scale);
+    hipLaunchKernelGGL((mit_attn_bwd_dkv_bf16_kernel<D>), gk, dim3(256), 0, st, a.q, a.dout, a.kv, a.lse, a.delta, a.dks, a.dvs, a.B, a.N,
+                       a.Np, a.Nk, a.Nkp, a.heads, a.C, a.c, a.scale, a.ns, a.qps);
+}
+int attn_bwd_bf16_launch(const AttnBf16Args& a, hipStream_t stream) {
+    if (a.D == 64) bwd_launch<64>(a, stream); else bwd_launch<32>(a, stream);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
