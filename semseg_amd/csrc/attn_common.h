@@ -51,6 +51,29 @@ __device__ __forceinline__ void store_transposed(const floatx16 (&acc)[D / 32], 
 }
 
 
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+template <int CH> __device__ __forceinline__ int img_slot(int row, int chunk) {
+    constexpr int RPB = 16 / CH;
+    const int R = row / RPB;
+    return R * 16 + ((((row % RPB) * CH) + chunk) ^ (R & 15));
+}
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int slot) { return *(const bf16x8*)(img + slot * 16); }
+
+// A operand X^T[col][row-perm] of a row-major [row][col] image: lane (li = col within the 32-wide tile, lh) gets rows
+// base + 8(e>>2) + 4 lh + (e&3), e = 0..7.
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int pitch, int base, int col0) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3, gsel = (lane >> 4) & 1, lh = lane >> 5;
+    const char* a0 = img + (base + 4 * lh + tq) * pitch + (col0 + gsel * 16 + 4 * tp) * 2;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 8 * pitch));
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+    return f;
+}
+
+
 // bf16 fast path (attention_bf16.hip)
 struct AttnBf16Args {
     const bf16 *q, *kv, *o, *dout; const float* lse; bf16 *out, *dq, *dkv; float *lse_out, *delta, *dks, *dvs;

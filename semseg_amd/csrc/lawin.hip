@@ -16,6 +16,14 @@
 #include "common.h"
 #include "colreduce.h"
 
+// bf16 MFMA window attention for head dims 16 / 32 / 64 (lawin_attn_mfma.hip)
+bool lawin_attn_mfma_ok(int D, const void* theta, int64_t ldt, const void* pg, int inter, const void* p2, int64_t ld2, const void* p3,
+                        int64_t ld3, const void* p4, int64_t ld4);
+int lawin_attn_fwd_mfma(const void* theta, int64_t ldt, const void* pg, void* y, int64_t ldy, float* lse, int B, int H, int W, int inter,
+                        int heads, hipStream_t stream);
+int lawin_attn_bwd_mfma(const void* theta, int64_t ldt, const void* pg, const void* y, int64_t ldy, const void* dy, int64_t lddy,
+                        const float* lse, void* dtheta, int64_t lddt, void* dpg, int B, int H, int W, int inter, int heads, hipStream_t stream);
+
 struct WinGeom { int B, H, W, nh, nw, r, st, pad, gh, gw; };
 static inline WinGeom win_geom(int B, int H, int W, int r) {
     WinGeom g; g.B = B; g.H = H; g.W = W; g.nh = H / 8; g.nw = W / 8; g.r = r; g.st = 8 / r; g.pad = 4 * (r - 1);
@@ -433,6 +441,8 @@ extern "C" int ss_lawin_attn_fwd(int dtype, const void* theta, int64_t ldt, cons
     WinGeom g = win_geom(B, H, W, 8);
     const int D = inter / heads;
     int rc = 0;
+    if (dtype == SS_BF16 && lawin_attn_mfma_ok(D, theta, ldt, pg, inter, y, ldy, nullptr, 0, nullptr, 0))
+        return lawin_attn_fwd_mfma(theta, ldt, pg, y, ldy, lse, B, H, W, inter, heads, stream);
     SS_DISPATCH(dtype, SS_D_SWITCH(D, rc = (attn_fwd_launch<T, DD>((const T*)theta, ldt, (const T*)pg, (T*)y, ldy, lse, g, inter, heads, stream))));
     return rc;
 }
@@ -445,6 +455,8 @@ extern "C" int ss_lawin_attn_bwd(int dtype, const void* theta, int64_t ldt, cons
     WinGeom g = win_geom(B, H, W, 8);
     const int D = inter / heads;
     int rc = 0;
+    if (dtype == SS_BF16 && lawin_attn_mfma_ok(D, theta, ldt, pg, inter, y, ldy, dy, lddy, dtheta, lddt) && aligned16(dpg))
+        return lawin_attn_bwd_mfma(theta, ldt, pg, y, ldy, dy, lddy, lse, dtheta, lddt, dpg, B, H, W, inter, heads, stream);
     SS_DISPATCH(dtype, SS_D_SWITCH(D, rc = (attn_bwd_launch<T, DD>((const T*)theta, ldt, (const T*)pg, (const T*)y, ldy, (const T*)dy, lddy, lse,
                                                                    (T*)dtheta, lddt, (T*)dpg, g, inter, heads, stream))));
     return rc;

@@ -273,3 +273,33 @@ def test_small_helpers(ops):
     assert torch.equal(out[:, 8:40].cpu(), x[:2].repeat_interleave(10, 0))
     with pytest.raises((RuntimeError, ValueError)):
         ops.add(x, x)                      # CPU tensors are refused: no fallback path
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,H,W,inter,heads', [(2, 16, 24, 64, 4), (1, 8, 16, 128, 4), (2, 16, 16, 128, 2), (1, 16, 8, 32, 8), (1, 8, 8, 64, 64)])
+def test_lawin_window_attention(ops, dtype, B, H, W, inter, heads):
+    """per (8x8 window, head) softmax(theta phi^T / sqrt(d)) g (modules/lawin.py:72-91) and its backward; head dims 16/32/64 take
+    the MFMA kernels in bf16, the others (and fp32) the vector-ALU kernels."""
+    d = inter // heads
+    nh, nw = H // 8, W // 8
+    nwin = B * nh * nw
+    theta, pg, dy = rnd(B * H * W, inter), rnd(nwin * 64, 2 * inter, seed=1), rnd(B * H * W, inter, seed=2)
+    tr, pr = q(theta, dtype).requires_grad_(True), q(pg, dtype).requires_grad_(True)
+    # image-ordered rows -> [window, head, 64, d]
+    tw = tr.view(B, nh, 8, nw, 8, heads, d).permute(0, 1, 3, 5, 2, 4, 6).reshape(nwin, heads, 64, d)
+    phi = pr[:, :inter].reshape(nwin, 64, heads, d).transpose(1, 2)
+    g = pr[:, inter:].reshape(nwin, 64, heads, d).transpose(1, 2)
+    yw = torch.softmax(tw @ phi.transpose(-1, -2) / math.sqrt(d), -1) @ g
+    ref = yw.view(B, nh, nw, heads, 8, 8, d).permute(0, 1, 4, 2, 5, 3, 6).reshape(B * H * W, inter)
+    ref.backward(q(dy, dtype))
+    y, lse = ops.lawin_attn_fwd(dev(theta, dtype), dev(pg, dtype), B, H, W, heads)
+    assert rel(y, ref) < _tol(dtype)
+    dth, dpg = ops.lawin_attn_bwd(dev(theta, dtype), dev(pg, dtype), y, dev(dy, dtype), lse, B, H, W, heads)
+    assert rel(dth, tr.grad) < _tol(dtype) * 2
+    assert rel(dpg, pr.grad) < _tol(dtype) * 2
+    # theta / y as channel slices of wider buffers (how LawinHead calls it)
+    wide = dev(rnd(B * H * W, inter + 16, seed=4), dtype)
+    y2, _ = ops.lawin_attn_fwd(wide[:, 8:8 + inter], dev(pg, dtype), B, H, W, heads)
+    tw2 = wide[:, 8:8 + inter].float().cpu().view(B, nh, 8, nw, 8, heads, d).permute(0, 1, 3, 5, 2, 4, 6).reshape(nwin, heads, 64, d)
+    ref2 = (torch.softmax(tw2 @ phi.detach().transpose(-1, -2) / math.sqrt(d), -1) @ g.detach()).view(B, nh, nw, heads, 8, 8, d)
+    assert rel(y2, ref2.permute(0, 1, 4, 2, 5, 3, 6).reshape(B * H * W, inter)) < _tol(dtype)
