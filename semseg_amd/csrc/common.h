@@ -87,10 +87,19 @@ __device__ __forceinline__ float group_max(float v, int lanes) {
 }
 
 // ---------------------------------------------------------------- math
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+// GELU(x) = x Phi(x), Phi(x) = 0.5 (1 + erf(x / sqrt 2)).  erfc(|z|) = poly(t) exp(-z^2), t = 1 / (1 + p |z|)
+// (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute): one exp and one reciprocal serve Phi AND the density term of the
+// derivative, instead of libm erff + expf (the GELU kernels are otherwise VALU-bound on an HBM-bound op).
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ez) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.f + 0.3275911f * z);
+    ez = __expf(-z * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float hc = 0.5f * poly * ez;                       // 0.5 erfc(|z|)
+    cdf = x >= 0.f ? 1.f - hc : hc;
 }
+__device__ __forceinline__ float gelu_erf(float x) { float cdf, ez; gelu_parts(x, cdf, ez); return x * cdf; }
+__device__ __forceinline__ float gelu_erf_grad(float x) { float cdf, ez; gelu_parts(x, cdf, ez); return cdf + x * 0.3989422804014327f * ez; }
 // Mish(x) = x * tanh(softplus(x)).  With e = exp(x) and n = e (e + 2):  tanh(log(1 + e)) = n / (n + 2)  (no cancellation),
 // 1 - tanh^2 = 4 (n + 1) / (n + 2)^2, sigmoid = e / (1 + e): one expf and two divisions instead of expf + log1pf + tanhf.
 // x > 20: Mish(x) = x to fp32 precision (torch's softplus threshold); x << 0: e underflows to 0 and both forms return 0.
