@@ -86,6 +86,22 @@ int ss_dwconv3_fwd(int dtype, const void* x, const float* w9c, const float* bias
 int ss_dwconv3_bwd(int dtype, const void* dy, const void* x, const float* w9c, const float* bias, void* g, float* dw_db,
                    int B, int H, int W, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
+/* ---- general depthwise k x k convolution on channels-last maps: ConvNeXt 7x7 s1 p3 (modules/convnext.py:27,39) and the TopFormer
+ * token-pyramid 3x3 / 5x5, stride 1 / 2 with the asymmetric AutoPadding of modules/layers.py:146-164 (modules/topformer.py:166-184).
+ * wkkc: tap-major [k*k][C] fp32.  act: 0 none, 1 GELU(erf), 2 ReLU, 3 ReLU6.  The data gradient (stride 1) is this entry point with
+ * flipped taps and padding k-1-pad.  ss_dwconvk_wgrad: dw_db = [(k*k + 1)][C] fp32 (taps, then the bias gradient); stride 1,
+ * symmetric padding, k in {3,5,7}; workspace >= 1024*(k*k+1)*C floats. */
+int ss_dwconvk_fwd(int dtype, const void* x, const float* wkkc, const float* bias, void* y, int B, int H, int W, int C, int k,
+                   int stride, int pad_top, int pad_left, int Ho, int Wo, int act, hipStream_t stream);
+int ss_dwconvk_wgrad(int dtype, const void* g, const void* x, float* dw_db, int B, int H, int W, int C, int k, int pad,
+                     float* workspace, int64_t ws_bytes, hipStream_t stream);
+/* out[r] = sum_c a[r][c] * b[r][c] (fp32): layer-scale gradient of modules/convnext.py:33-35,46-47 from the folded weight gradient */
+int ss_rowdot_f32(const float* a, const float* b, float* out, int rows, int C, hipStream_t stream);
+
+/* nn.GELU between pw_conv1 and pw_conv2 (modules/convnext.py:30,43): a = GELU(z);  dz = da * GELU'(z).  n elements, n % 8 == 0. */
+int ss_gelu_fwd(int dtype, const void* z, void* a, int64_t n, hipStream_t stream);
+int ss_gelu_bwd(int dtype, const void* da, const void* z, void* dz, int64_t n, hipStream_t stream);
+
 /* ---- MiT efficient self-attention (modules/segformer.py:32-39): softmax(q k^T * scale) v without the [B,h,N,Nk] matrix.
  * q,o: [B,N,heads*D]; kv: [B,Nk,2*heads*D] (k | v); lse: [B,heads,round32(N)] fp32 (base-2 log-sum-exp); D in {32,64}. */
 int64_t ss_mit_attn_fwd_workspace(int dtype, int B, int Nk, int heads, int D);
@@ -168,6 +184,29 @@ int ss_dice_bwd(int dtype, const int64_t* labels, const float* coef_hit, const f
  * first maximum wins ties. */
 int ss_confusion_update(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,
                         int64_t* cm, int B, int C, int H, int W, hipStream_t stream);
+
+/* ---- core/decoder.py:49-59 tail on channels-last maps.  x = LawinHead output [B,H4,W4,2oc].  The host runs two GEMMs on x:
+ * z9 [rows, ld9 >= 9*oc] = x . Wd (ConvTranspose2d k3 s4 weight as [(o,dy,dx)][c], modules/blocks.py:224-234) and bs [rows, oc] =
+ * conv1x1(x) + b (feature_reducer, core/decoder.py:38-47; the 1x1 conv commutes with the nearest up-sampling of :52-58).
+ * ss_decoder_stats: BatchNorm2d statistics of the (4H4-1)x(4W4-1) deconvolved map (stride 4 > kernel 3: gaps hold the bias only);
+ * stats = [2*oc] (mean, rstd), running buffers updated as torch does.  ss_decoder_combine_fwd: prod [B,(4H4-1),(4W4-1),oc] =
+ * ReLU(BN(deconv)) * nearest-up(bs).  ss_decoder_combine_bwd: dz9 (ld9 columns), dbs, dgb = [2*oc] (dgamma, dbeta), dbias_grad [oc];
+ * workspace >= (1024*2*oc + 4*oc) floats.  oc <= 32, H4, W4 <= 1024. */
+int ss_decoder_stats(int dtype, const void* z9, int64_t ld9, int B, int H4, int W4, int oc, const float* dbias, float eps,
+                     float momentum, float* stats, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float* workspace, int64_t ws_bytes, hipStream_t stream);
+int ss_decoder_combine_fwd(int dtype, const void* z9, int64_t ld9, const void* bs, int64_t ldb, const float* dbias, const float* stats,
+                           const float* gamma, const float* beta, void* prod, int B, int H4, int W4, int oc, hipStream_t stream);
+int ss_decoder_combine_bwd(int dtype, const void* dprod, const void* z9, int64_t ld9, const void* bs, int64_t ldb, const float* dbias,
+                           const float* stats, const float* gamma, const float* beta, int training, void* dz9, void* dbs, float* dgb,
+                           float* dbias_grad, int B, int H4, int W4, int oc, float* workspace, int64_t ws_bytes, hipStream_t stream);
+/* ---- core/dnet.py:45-51 + MultilabelClassifier (modules/layers.py:25-43): nearest resize (Hd,Wd) -> (H,W) (torch's float index
+ * rule), 1x1 conv oc -> nc + bias, Softmax2d.  probs / dprobs: NCHW [B,nc,H,W]; wt [nc][oc], bt [nc] fp32.
+ * ss_terminator_bwd: dprod [B,Hd,Wd,oc], dw_db = [nc*oc + nc] fp32; workspace >= 1024*(nc*oc + nc) floats. */
+int ss_terminator_fwd(int dtype, const void* prod, const float* wt, const float* bt, void* probs, int B, int Hd, int Wd, int H, int W,
+                      int oc, int nc, hipStream_t stream);
+int ss_terminator_bwd(int dtype, const void* dprobs, const void* prod, const float* wt, const float* bt, void* dprod, float* dw_db,
+                      int B, int Hd, int Wd, int H, int W, int oc, int nc, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
 /* ---- optimizer step right after the gradient all-reduce: AdaBound as configured in train.py:53-58
  * (torch_optimizer.AdaBound, absent here: restated from Luo et al. 2019, parity unpinned) over FLAT fp32 buffers -- one launch

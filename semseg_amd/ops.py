@@ -623,3 +623,124 @@ def sum_slices(x, nslices, slice_stride, C, bvec=None, rows_per_image=0):
     out = torch.empty((rows, C), dtype=x.dtype, device=dev)
     check(lib().ss_sum_slices(dt(x), _p(x), ld, nslices, slice_stride, _p(bvec), rows_per_image, _p(out), rows, C, _stream()))
     return out
+
+
+# ------------------------------------------------------------------ general depthwise conv / GELU (ConvNeXt, TopFormer)
+def dwconvk_fwd(x, wkkc, bias, B, H, W, k, stride=1, pad_top=None, pad_left=None, Ho=None, Wo=None, act=0):
+    """x [B*H*W, C] -> y [B*Ho*Wo, C];  wkkc: tap-major [k*k, C] fp32.  Default: symmetric padding k//2, stride 1."""
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    if ld != C or rows != B * H * W:
+        raise ValueError('dwconvk_fwd: x must be dense [B*H*W, C]')
+    pad_top = k // 2 if pad_top is None else pad_top
+    pad_left = k // 2 if pad_left is None else pad_left
+    Ho = (H + 2 * pad_top - k) // stride + 1 if Ho is None else Ho
+    Wo = (W + 2 * pad_left - k) // stride + 1 if Wo is None else Wo
+    _f32(wkkc, 'wkkc', k * k * C), _f32(bias, 'bias', C)
+    y = torch.empty((B * Ho * Wo, C), dtype=x.dtype, device=dev)
+    check(lib().ss_dwconvk_fwd(dt(x), _p(x), _p(wkkc), _p(bias), _p(y), B, H, W, C, k, stride, pad_top, pad_left, Ho, Wo, act, _stream()))
+    return y
+
+
+def dwconvk_wgrad(g, x, B, H, W, k):
+    """-> dw_db [(k*k + 1), C] fp32 (taps tap-major, then the bias gradient); stride 1, padding k//2."""
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    if ld != C or rows != B * H * W or g.shape != x.shape or g.dtype != x.dtype or not g.is_contiguous():
+        raise ValueError('dwconvk_wgrad: bad x / g')
+    out = torch.empty((k * k + 1, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, COLRED_BLOCKS * (k * k + 1) * C * 4)
+    check(lib().ss_dwconvk_wgrad(dt(x), _p(g), _p(x), _p(out), B, H, W, C, k, k // 2, _p(ws), ws.numel(), _stream()))
+    return out
+
+
+def rowdot_f32(a, b):
+    _dev(a)
+    rows, C = a.shape
+    _f32(a, 'a'), _f32(b, 'b', rows * C)
+    out = torch.empty(rows, dtype=torch.float32, device=a.device)
+    check(lib().ss_rowdot_f32(_p(a), _p(b), _p(out), rows, C, _stream()))
+    return out
+
+
+def gelu_fwd(z):
+    _dev(z)
+    if not z.is_contiguous():
+        raise ValueError('gelu_fwd: z must be contiguous')
+    a = torch.empty_like(z)
+    check(lib().ss_gelu_fwd(dt(z), _p(z), _p(a), z.numel(), _stream()))
+    return a
+
+
+def gelu_bwd(da, z):
+    _dev(z)
+    if not z.is_contiguous() or not da.is_contiguous() or da.shape != z.shape or da.dtype != z.dtype:
+        raise ValueError('gelu_bwd: da / z must be contiguous and alike')
+    dz = torch.empty_like(z)
+    check(lib().ss_gelu_bwd(dt(z), _p(da), _p(z), _p(dz), z.numel(), _stream()))
+    return dz
+
+
+# ------------------------------------------------------------------ Decoder / DNet tail
+def decoder_stats(z9, B, H4, W4, oc, dbias, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt=None):
+    dev = _dev(z9)
+    rows, _, ld9 = _mat(z9, 'z9')
+    if rows != B * H4 * W4:
+        raise ValueError('decoder_stats: bad z9')
+    _f32(dbias, 'dbias', oc)
+    stats = torch.empty(2 * oc, dtype=torch.float32, device=dev)
+    ws = workspace(dev, COLRED_BLOCKS * 2 * ld9 * 4)
+    check(lib().ss_decoder_stats(dt(z9), _p(z9), ld9, B, H4, W4, oc, _p(dbias), eps, momentum, _p(stats), _p(running_mean), _p(running_var),
+                                 _p(nbt), _p(ws), ws.numel(), _stream()))
+    return stats
+
+
+def decoder_combine_fwd(z9, bs, dbias, stats, gamma, beta, B, H4, W4, oc):
+    dev = _dev(z9)
+    _, _, ld9 = _mat(z9, 'z9')
+    _, _, ldb = _mat(bs, 'bs')
+    prod = torch.empty((B * (4 * H4 - 1) * (4 * W4 - 1), oc), dtype=z9.dtype, device=dev)
+    check(lib().ss_decoder_combine_fwd(dt(z9), _p(z9), ld9, _p(bs), ldb, _p(dbias), _p(stats), _p(gamma), _p(beta), _p(prod), B, H4, W4, oc, _stream()))
+    return prod
+
+
+def decoder_combine_bwd(dprod, z9, bs, dbias, stats, gamma, beta, training, B, H4, W4, oc):
+    """-> dz9 (like z9), dbs (like bs), dgb [2*oc] (dgamma, dbeta), d(deconv bias) [oc]."""
+    dev = _dev(z9)
+    _, _, ld9 = _mat(z9, 'z9')
+    _, _, ldb = _mat(bs, 'bs')
+    if not dprod.is_contiguous() or dprod.dtype != z9.dtype or dprod.shape != (B * (4 * H4 - 1) * (4 * W4 - 1), oc) or not z9.is_contiguous() or not bs.is_contiguous():
+        raise ValueError('decoder_combine_bwd: bad tensors')
+    dz9, dbs = torch.empty_like(z9), torch.empty_like(bs)
+    dgb = torch.empty(2 * oc, dtype=torch.float32, device=dev)
+    dbg = torch.empty(oc, dtype=torch.float32, device=dev)
+    ws = workspace(dev, (COLRED_BLOCKS * 2 * oc + 4 * oc) * 4)
+    check(lib().ss_decoder_combine_bwd(dt(z9), _p(dprod), _p(z9), ld9, _p(bs), ldb, _p(dbias), _p(stats), _p(gamma), _p(beta), int(training),
+                                       _p(dz9), _p(dbs), _p(dgb), _p(dbg), B, H4, W4, oc, _p(ws), ws.numel(), _stream()))
+    return dz9, dbs, dgb, dbg
+
+
+def terminator_fwd(prod, wt, bt, B, Hd, Wd, H, W):
+    """prod [B*Hd*Wd, oc] -> probabilities NCHW [B, nc, H, W]."""
+    dev = _dev(prod)
+    nc, oc = wt.shape
+    _f32(wt, 'wt'), _f32(bt, 'bt', nc)
+    if not prod.is_contiguous() or prod.shape != (B * Hd * Wd, oc):
+        raise ValueError('terminator_fwd: bad prod')
+    probs = torch.empty((B, nc, H, W), dtype=prod.dtype, device=dev)
+    check(lib().ss_terminator_fwd(dt(prod), _p(prod), _p(wt), _p(bt), _p(probs), B, Hd, Wd, H, W, oc, nc, _stream()))
+    return probs
+
+
+def terminator_bwd(dprobs, prod, wt, bt, B, Hd, Wd, H, W):
+    """-> dprod [B*Hd*Wd, oc], dW [nc, oc] fp32, db [nc] fp32."""
+    dev = _dev(prod)
+    nc, oc = wt.shape
+    if not dprobs.is_contiguous() or dprobs.dtype != prod.dtype or dprobs.shape != (B, nc, H, W):
+        raise ValueError('terminator_bwd: dprobs must be contiguous NCHW like the probabilities')
+    dprod = torch.empty_like(prod)
+    out = torch.empty(nc * oc + nc, dtype=torch.float32, device=dev)
+    ws = workspace(dev, COLRED_BLOCKS * (nc * oc + nc) * 4)
+    check(lib().ss_terminator_bwd(dt(prod), _p(dprobs), _p(prod), _p(wt), _p(bt), _p(dprod), _p(out), B, Hd, Wd, H, W, oc, nc, _p(ws), ws.numel(),
+                                  _stream()))
+    return dprod, out[:nc * oc].view(nc, oc), out[nc * oc:]

@@ -93,3 +93,53 @@ def lawin_shapes(in_channels, embed_dim=512, out_channels=8):
     out['linear_pred.weight'] = (out_channels, e, 1, 1)
     out['linear_pred.bias'] = (out_channels,)
     return out
+
+
+CONVNEXT_VARIANTS = {      # modules/convnext.py:72-77
+    'X': ((2, 2, 4, 2), (32, 64, 128, 256)), 'T': ((3, 3, 9, 3), (96, 192, 384, 768)),
+    'S': ((3, 3, 27, 3), (96, 192, 384, 768)), 'B': ((3, 3, 27, 3), (128, 256, 512, 1024)),
+}
+
+
+def convnext_shapes(variant='T', in_channels=3):
+    """modules/convnext.py:79-130."""
+    depths, dims = CONVNEXT_VARIANTS[variant]
+    out = {'downsample_layers.0.0.weight': (dims[0], in_channels, 4, 4), 'downsample_layers.0.0.bias': (dims[0],)}
+    _ln(out, 'downsample_layers.0.1', dims[0])
+    for i in range(1, 4):
+        _ln(out, f'downsample_layers.{i}.0', dims[i - 1])
+        out[f'downsample_layers.{i}.1.weight'] = (dims[i], dims[i - 1], 2, 2)
+        out[f'downsample_layers.{i}.1.bias'] = (dims[i],)
+    for i in range(4):
+        c = dims[i]
+        for j in range(depths[i]):
+            p = f'stages.{i}.{j}'
+            out[p + '.gamma'] = (c,)
+            out[p + '.dw_conv.weight'] = (c, 1, 7, 7)
+            out[p + '.dw_conv.bias'] = (c,)
+            _ln(out, p + '.norm', c)
+            _lin(out, p + '.pw_conv1', c, 4 * c)
+            _lin(out, p + '.pw_conv2', 4 * c, c)
+        _ln(out, f'norm{i}', c)
+    return out
+
+
+def decoder_shapes(in_channels, out_channels, embed_dim=512):
+    """core/decoder.py:11-47."""
+    out = {'decoder.' + k: v for k, v in lawin_shapes(in_channels, embed_dim, 2 * out_channels).items()}
+    out['deconvolution.net.0.weight'] = (2 * out_channels, out_channels, 3, 3)
+    out['deconvolution.net.0.bias'] = (out_channels,)
+    _bn(out, 'deconvolution.net.1', out_channels)
+    out['feature_reducer.net.p_conv.conv.weight'] = (out_channels, 2 * out_channels, 1, 1)
+    out['feature_reducer.net.p_conv.conv.bias'] = (out_channels,)
+    return out
+
+
+def dnet_shapes(image_channels=3, num_classes=6, embed_dim=256, stem_code='T'):
+    """core/dnet.py:9-34."""
+    out = {'encoder.encoder.' + k: v for k, v in convnext_shapes(stem_code, image_channels).items()}
+    dims = list(CONVNEXT_VARIANTS[stem_code][1])
+    out.update({'decoder.' + k: v for k, v in decoder_shapes(dims, 2 * num_classes, embed_dim).items()})
+    out['terminator.terminator.0.weight'] = (num_classes, 2 * num_classes, 1, 1)
+    out['terminator.terminator.0.bias'] = (num_classes,)
+    return out

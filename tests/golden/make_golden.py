@@ -19,7 +19,7 @@ torch.manual_seed(0)
 torch.set_num_threads(8)
 
 from semseg_amd.detinit import det_fill_, det_input, det_labels  # noqa: E402
-from oracle import mit as omit, lawin as olawin, losses as olosses  # noqa: E402
+from oracle import mit as omit, lawin as olawin, losses as olosses, convnext as oconvnext  # noqa: E402
 from modules.segformer import SegFormer  # noqa: E402  (reference)
 from modules.lawin import LawinHead  # noqa: E402  (reference)
 from loss.seg_loss import OhemCrossEntropyLoss, DiceLoss, dice_loss  # noqa: E402  (reference)
@@ -227,7 +227,70 @@ def gen_losses():
     np.savez_compressed(os.path.join(HERE, 'losses.npz'), **save)
 
 
+def gen_convnext():
+    from modules.convnext import ConvNeXt  # reference
+    enc = det_fill_(ConvNeXt('X')).eval()
+    x = det_input('cnx.x', (2, 3, 64, 64))
+    outs = enc(x)
+    projs = [det_input(f'cnx.proj{i}', o.shape, -1, 1) for i, o in enumerate(outs)]
+    sum((o * p).sum() for o, p in zip(outs, projs)).backward()
+    grads = {k: p.grad for k, p in enc.named_parameters()}
+    sd = grad_sd(detached_sd(enc))
+    oouts = oconvnext.convnext_forward(sd, x, 'X')
+    sum((o * p).sum() for o, p in zip(oouts, projs)).backward()
+    keys = ['downsample_layers.0.0.weight', 'downsample_layers.0.1.weight', 'downsample_layers.2.0.bias', 'downsample_layers.2.1.weight',
+            'stages.0.0.dw_conv.weight', 'stages.0.0.dw_conv.bias', 'stages.0.1.norm.weight', 'stages.1.0.pw_conv1.weight',
+            'stages.1.1.pw_conv2.weight', 'stages.1.1.pw_conv2.bias', 'stages.2.3.gamma', 'stages.0.0.gamma', 'stages.3.1.dw_conv.weight',
+            'norm0.weight', 'norm3.bias']
+    save = {}
+    for i in range(4):
+        check(f'cnx.out{i}', oouts[i], outs[i])
+        save[f'out{i}'] = np_(outs[i])
+    for k in keys:
+        check(f'cnx.grad.{k}', sd[k].grad, grads[k], 5e-5)
+        save['grad.' + k] = np_(grads[k])
+    np.savez_compressed(os.path.join(HERE, 'convnext_x_64.npz'), **save)
+
+
+def gen_dnet():
+    """DNet(3, 6, embed_dim=128, stem 'X') in TRAINING mode (batch-stat BatchNorms, Dropout2d p=0), 2x3x128x128: probabilities,
+    Tversky-Dice loss and a few gradients; running buffers after the step."""
+    from core.dnet import DNet  # reference
+    net = det_fill_(DNet(3, 6, embed_dim=128, stem_code='X')).train()
+    net.decoder.decoder.dropout.p = 0.0
+    sd0 = detached_sd(net)
+    x = det_input('dnet.x', (2, 3, 128, 128))
+    lab = det_labels('dnet.lab', (2, 128, 128), 6, cell=8)
+    probs = net(x)
+    loss = DiceLoss(0.5, False, 6)(probs, lab)
+    loss.backward()
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    sd = grad_sd(sd0)
+    oprobs = oconvnext.dnet_forward(sd, x, 'X', training=True)
+    oloss = olosses.tversky_dice(oprobs, lab, 6, 0.5, False)
+    oloss.backward()
+    check('dnet.probs', oprobs, probs)
+    check('dnet.loss', oloss, loss, 1e-6)
+    keys = ['terminator.terminator.0.weight', 'terminator.terminator.0.bias', 'decoder.deconvolution.net.0.weight',
+            'decoder.deconvolution.net.1.weight', 'decoder.deconvolution.net.1.bias', 'decoder.feature_reducer.net.p_conv.conv.weight',
+            'decoder.feature_reducer.net.p_conv.conv.bias', 'decoder.decoder.linear_pred.weight', 'decoder.decoder.cat.conv.weight',
+            'encoder.encoder.stages.3.1.pw_conv2.weight', 'encoder.encoder.stages.0.0.dw_conv.weight', 'encoder.encoder.stages.1.0.gamma',
+            'encoder.encoder.downsample_layers.0.0.weight']
+    save = {'probs': np_(probs), 'loss': np_(loss)}
+    for k in keys:
+        check(f'dnet.grad.{k}', sd[k].grad, grads[k], 1e-4)
+        save['grad.' + k] = np_(grads[k])
+    after = net.state_dict()
+    for k in ('decoder.deconvolution.net.1.running_mean', 'decoder.deconvolution.net.1.running_var', 'decoder.deconvolution.net.1.num_batches_tracked'):
+        check(f'dnet.after.{k}', sd[k].float(), after[k].float())
+        save['after.' + k] = np_(after[k])
+    np.savez_compressed(os.path.join(HERE, 'dnet_x_128.npz'), **save)
+
+
 if __name__ == '__main__':
-    for fn in (gen_mit, lambda: gen_head(False), lambda: gen_head(True), gen_segmentor, gen_losses):
+    only = sys.argv[1:]
+    gens = {'mit': gen_mit, 'head_eval': lambda: gen_head(False), 'head_train': lambda: gen_head(True), 'segmentor': gen_segmentor,
+            'losses': gen_losses, 'convnext': gen_convnext, 'dnet': gen_dnet}
+    for fn in [g for n, g in gens.items() if not only or n in only]:
         fn()
     print('golden vectors written to', HERE)

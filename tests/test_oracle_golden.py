@@ -123,3 +123,35 @@ def test_metrics_against_sklearn():
     assert abs(d['Global Accuracy'] - (pred == y).mean()) < 1e-6
     lg = ometrics.loggable(cm.numpy(), ignore_index=0)
     assert abs(lg['Micro_Accuracy'] - np.diag(cm.numpy()).mean()) < 1e-3
+
+
+def test_convnext_x(golden_dir):
+    from oracle import convnext as oconvnext
+    g = np.load(os.path.join(golden_dir, 'convnext_x_64.npz'))
+    sd = grad_sd(det_state_dict(shapes.convnext_shapes('X', 3)))
+    x = det_input('cnx.x', (2, 3, 64, 64))
+    outs = oconvnext.convnext_forward(sd, x, 'X')
+    projs = [det_input(f'cnx.proj{i}', o.shape, -1, 1) for i, o in enumerate(outs)]
+    sum((o * p).sum() for o, p in zip(outs, projs)).backward()
+    for i in range(4):
+        assert rel(outs[i].detach(), g[f'out{i}']) < 2e-5
+    for k in g.files:
+        if k.startswith('grad.'):
+            assert rel(sd[k[5:]].grad, g[k]) < 5e-5, k
+
+
+def test_dnet_x_training_step(golden_dir):
+    from oracle import convnext as oconvnext
+    g = np.load(os.path.join(golden_dir, 'dnet_x_128.npz'))
+    sd = grad_sd(det_state_dict(shapes.dnet_shapes(3, 6, 128, 'X')))
+    x = det_input('dnet.x', (2, 3, 128, 128))
+    lab = det_labels('dnet.lab', (2, 128, 128), 6, cell=8)
+    probs = oconvnext.dnet_forward(sd, x, 'X', training=True)
+    loss = olosses.tversky_dice(probs, lab, 6, 0.5, False)
+    loss.backward()
+    assert probs.shape == (2, 6, 128, 128) and rel(probs.detach(), g['probs']) < 2e-5 and rel(loss.detach(), g['loss']) < 1e-5
+    for k in g.files:
+        if k.startswith('grad.'):
+            assert rel(sd[k[5:]].grad, g[k]) < 2e-4, k
+        if k.startswith('after.'):
+            assert rel(sd[k[6:]].float(), g[k].astype(np.float32)) < 1e-5, k
