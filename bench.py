@@ -32,6 +32,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='mit_lawin', choices=['mit_lawin', 'dnet'],
+                    help="mit_lawin = BASELINE configs[1] (the headline); dnet = configs[2] per-GPU step (DNet-T, embed 256, batch 8, Dice loss)")
     ap.add_argument('--variant', default='B2')
     ap.add_argument('--embed', type=int, default=512)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
@@ -239,14 +241,19 @@ def main():
 
     T = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     set_compute_dtype(T)
-    net = SegFormerLawin(a.variant, a.embed, 6)
-    det_fill_(net.encoder), det_fill_(net.decoder)
+    if a.workload == 'dnet':
+        from semseg_amd.decoder import DNet
+        from semseg_amd.loss import DiceLoss
+        net = det_fill_(DNet(3, 6, embed_dim=256, stem_code='T'))
+    else:
+        net = SegFormerLawin(a.variant, a.embed, 6)
+        det_fill_(net.encoder), det_fill_(net.decoder)
     net = net.to(dev).train()
     broadcast_module_state(net)
     flat = FlatParams(net)
     reducer = GradReducer(flat)
     opt = AdaBound(flat, lr=1e-3, final_lr=0.1)
-    crit = OhemCrossEntropyLoss(0, 0.7, 0.1)
+    crit = DiceLoss(0.5, False, 6) if a.workload == 'dnet' else OhemCrossEntropyLoss(0, 0.7, 0.1)
     met = SegmentationMetrics(6, ignore_index=0).to(dev)
     x, lab = synthetic_batch(a.batch, a.size, rank, dev)
 
@@ -293,10 +300,12 @@ def main():
             dist.destroy_process_group()
         return
     ms = 1e3 * dt / a.steps
-    res = {'metric': 'train images/sec @1024x1024 (MiT-B2+Lawin)', 'value': a.batch * world * a.steps / dt, 'unit': 'images/s',
+    res = {'metric': 'train images/sec @1024x1024 (DNet ConvNeXt-T)' if a.workload == 'dnet' else 'train images/sec @1024x1024 (MiT-B2+Lawin)', 'value': a.batch * world * a.steps / dt, 'unit': 'images/s',
            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-           'config': {'workload': f'configs[1]: SegFormer MiT-{a.variant} + LawinHead({a.embed}, 6 cls) training step '
+           'config': {'workload': (f'configs[2] per-GPU step: DNet(ConvNeXt-T + Decoder(embed 256), 6 cls) training step (fwd + Dice + confusion '
+                                   f'matrix + bwd + grad all-reduce + AdaBound), {a.size}x{a.size}') if a.workload == 'dnet' else
+                                  f'configs[1]: SegFormer MiT-{a.variant} + LawinHead({a.embed}, 6 cls) training step '
                                   f'(fwd + OHEM-CE + confusion matrix + bwd + grad all-reduce + AdaBound), {a.size}x{a.size}',
                       'per_gpu_batch': a.batch, 'global_batch': a.batch * world, 'parallelism': f'dp{world}',
                       'weights': 'deterministic random init'},
