@@ -32,7 +32,8 @@ int ss_version(void);
  * modules/segformer.py:13-15,23,32,40,59,61 (q, kv, proj, fc1, fc2); :18,29 (sr conv as patch GEMM); :70-80 (PatchEmbed
  * conv as im2col GEMM); modules/lawin.py:10,14 (MLP.proj), :49-53,72-80 (g/theta/phi/conv_out), :100 (ConvModule.conv),
  * :137 (linear_pred).
- * C[M,N] = (A[M,K] . B[N,K]^T + bias[N]) * rowscale[row / rows_per_scale] + res[M,N];  act: 0 none, 1 GELU(erf) (before scale).
+ * C[M,N] = act(A[M,K] . B[N,K]^T + bias[N]) * rowscale[row / rows_per_scale] + res[M,N];  act: 0 none, 1 GELU(erf), 2 ReLU, 3 ReLU6,
+ * 4 h-sigmoid, 5 sigmoid (the conv-BN-act blocks of modules/topformer.py with BN folded into B and bias in eval mode).
  * out_f32 != 0 stores C (and reads res) as fp32 even for bf16 operands. */
 int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldr,
@@ -207,6 +208,20 @@ int ss_terminator_fwd(int dtype, const void* prod, const float* wt, const float*
                       int oc, int nc, hipStream_t stream);
 int ss_terminator_bwd(int dtype, const void* dprobs, const void* prod, const float* wt, const float* bt, void* dprod, float* dw_db,
                       int B, int Hd, int Wd, int H, int W, int oc, int nc, float* workspace, int64_t ws_bytes, hipStream_t stream);
+
+/* ---- TopFormer token pyramid (modules/topformer.py, modules/heads.py, core/models.py), inference.
+ * ss_im2col_ex: im2col with the asymmetric AutoPadding of modules/layers.py:146-164 (3x3 / s2 stem, :213-250).
+ * ss_avgpool: adaptive_avg_pool2d with exact win x win windows (PyramidPoolAgg :527-552), y may be a channel slice of the concat buffer.
+ * ss_act: y = act(x) (codes as ss_gemm_nt; the 'ACN' projection :394-409).  ss_inject_fuse: InjectionDotSum.forward :640-673,
+ * out = local * bilinear(gact) + bilinear(gemb).  ss_bilinear_add: y += bilinear(x) (UniRes + Sum, modules/heads.py:60-106). */
+int ss_im2col_ex(int dtype, const void* x, void* col, int B, int H, int W, int C, int k, int s, int pad_top, int pad_left, int Ho,
+                 int Wo, int Kp, hipStream_t stream);
+int ss_avgpool(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C, int win, hipStream_t stream);
+int ss_act(int dtype, const void* x, void* y, int64_t n, int act, hipStream_t stream);
+int ss_inject_fuse(int dtype, const void* local, int64_t ldl, const void* gact, int64_t lda, const void* gemb, int64_t lde, void* out,
+                   int64_t ldo, int B, int hl, int wl, int hg, int wg, int C, hipStream_t stream);
+int ss_bilinear_add(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
+                    hipStream_t stream);
 
 /* ---- optimizer step right after the gradient all-reduce: AdaBound as configured in train.py:53-58
  * (torch_optimizer.AdaBound, absent here: restated from Luo et al. 2019, parity unpinned) over FLAT fp32 buffers -- one launch

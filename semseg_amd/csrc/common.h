@@ -100,6 +100,19 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ez) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { float cdf, ez; gelu_parts(x, cdf, ez); return x * cdf; }
 __device__ __forceinline__ float gelu_erf_grad(float x) { float cdf, ez; gelu_parts(x, cdf, ez); return cdf + x * 0.3989422804014327f * ez; }
+// epilogue activation codes shared by the GEMM / depthwise / elementwise kernels: 0 none, 1 GELU(erf), 2 ReLU, 3 ReLU6,
+// 4 h-sigmoid = ReLU6(x + 3) / 6 (activation/activations.py), 5 sigmoid
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case 1: return gelu_erf(v);
+        case 2: return fmaxf(v, 0.f);
+        case 3: return fminf(fmaxf(v, 0.f), 6.f);
+        case 4: return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        case 5: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
 // Mish(x) = x * tanh(softplus(x)).  With e = exp(x) and n = e (e + 2):  tanh(log(1 + e)) = n / (n + 2)  (no cancellation),
 // 1 - tanh^2 = 4 (n + 1) / (n + 2)^2, sigmoid = e / (1 + e): one expf and two divisions instead of expf + log1pf + tanhf.
 // x > 20: Mish(x) = x to fp32 precision (torch's softplus threshold); x << 0: e underflows to 0 and both forms return 0.

@@ -39,9 +39,7 @@ __global__ __launch_bounds__(256) void dwconvk_fwd_kernel(const T* __restrict__ 
         F8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float v = u[e];
-            if (act == 1) v = gelu_erf(v); else if (act == 2) v = fmaxf(v, 0.f); else if (act == 3) v = fminf(fmaxf(v, 0.f), 6.f);
-            o.v[e] = v;
+            o.v[e] = apply_act(u[e], act);
         }
         store8(y + p * C + c, o);
     }

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 float v = acc[a][b][r];
                 if (!TRANS) {
                     v += bv;
-                    if (p.act == 1) v = gelu_erf(v);
+                    v = apply_act(v, p.act);
                     if (p.rowscale) v *= p.rowscale[row / p.rows_per_scale];
                     if (R) v += to_f(R[row * p.ldr + col]);
                 }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(FastGemm p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[a][b][4 * g + e] + bv[e];
-                    if (p.act == 1) v = gelu_erf(v);
+                    v = apply_act(v, p.act);
                     v = v * rs + (float)rv[e];
                     o[e] = (bf16)v;
                 }

@@ -32,7 +32,7 @@ def det_tensor(name, shape, kind=None):
 
 def det_state_dict(shapes):
     """shapes: {key: shape}  ->  {key: torch tensor}."""
-    return {k: torch.from_numpy(det_tensor(k, s)) for k, s in sorted(shapes.items())}
+    return {k: torch.from_numpy(np.asarray(det_tensor(k, s))) for k, s in sorted(shapes.items())}
 
 
 def det_fill_(module, prefix=''):

@@ -246,7 +246,7 @@ def dwconv3_bwd(dy, x, w9c, bias, B, H, W, act=0):
 
 
 # ------------------------------------------------------------------ MiT attention
-def mit_attn_fwd(q, kv, B, N, Nk, heads):
+def mit_attn_fwd(q, kv, B, N, Nk, heads, scale=None):
     """q [B*N, C], kv [B*Nk, 2C] -> o [B*N, C], lse [B, heads, round32(N)]."""
     dev = _dev(q)
     rows, C, ld = _mat(q, 'q')
@@ -258,7 +258,8 @@ def mit_attn_fwd(q, kv, B, N, Nk, heads):
     lse = torch.empty((B, heads, (N + 31) // 32 * 32), dtype=torch.float32, device=dev)
     nbytes = lib().ss_mit_attn_fwd_workspace(dt(q), B, Nk, heads, D)
     ws = workspace(dev, nbytes)
-    check(lib().ss_mit_attn_fwd(dt(q), _p(q), _p(kv), _p(o), _p(lse), B, N, Nk, heads, D, float(D) ** -0.5, _p(ws), ws.numel(), _stream()))
+    check(lib().ss_mit_attn_fwd(dt(q), _p(q), _p(kv), _p(o), _p(lse), B, N, Nk, heads, D, float(D) ** -0.5 if scale is None else float(scale),
+                                _p(ws), ws.numel(), _stream()))
     return o, lse
 
 
@@ -744,3 +745,61 @@ def terminator_bwd(dprobs, prod, wt, bt, B, Hd, Wd, H, W):
     check(lib().ss_terminator_bwd(dt(prod), _p(dprobs), _p(prod), _p(wt), _p(bt), _p(dprod), _p(out), B, Hd, Wd, H, W, oc, nc, _p(ws), ws.numel(),
                                   _stream()))
     return dprod, out[:nc * oc].view(nc, oc), out[nc * oc:]
+
+
+# ------------------------------------------------------------------ TopFormer helpers
+def im2col_ex(x, B, H, W, C, k, s, pad_top, pad_left, Ho, Wo):
+    dev = _dev(x)
+    if not x.is_contiguous() or x.numel() != B * H * W * C:
+        raise ValueError('im2col_ex: bad x')
+    Kp = (k * k * C + 7) // 8 * 8
+    col = torch.empty((B * Ho * Wo, Kp), dtype=x.dtype, device=dev)
+    check(lib().ss_im2col_ex(dt(x), _p(x), _p(col), B, H, W, C, k, s, pad_top, pad_left, Ho, Wo, Kp, _stream()))
+    return col
+
+
+def avgpool(x, B, H, W, win, out=None):
+    dev = _dev(x)
+    rows, C, ldx = _mat(x, 'x')
+    if rows != B * H * W:
+        raise ValueError('avgpool: bad x')
+    ro = B * (H // win) * (W // win)
+    if out is None:
+        out = torch.empty((ro, C), dtype=x.dtype, device=dev)
+    r2, C2, ldy = _mat(out, 'out')
+    if (r2, C2) != (ro, C) or out.dtype != x.dtype:
+        raise ValueError('avgpool: bad out')
+    check(lib().ss_avgpool(dt(x), _p(x), ldx, _p(out), ldy, B, H, W, C, win, _stream()))
+    return out
+
+
+def act(x, code):
+    _dev(x)
+    if not x.is_contiguous():
+        raise ValueError('act: x must be contiguous')
+    y = torch.empty_like(x)
+    check(lib().ss_act(dt(x), _p(x), _p(y), x.numel(), code, _stream()))
+    return y
+
+
+def inject_fuse(local, gact, gemb, B, hl, wl, hg, wg):
+    dev = _dev(local)
+    rows, C, ldl = _mat(local, 'local')
+    ra, Ca, lda = _mat(gact, 'gact')
+    re_, Ce, lde = _mat(gemb, 'gemb')
+    if rows != B * hl * wl or ra != B * hg * wg or re_ != ra or Ca != C or Ce != C or gact.dtype != local.dtype or gemb.dtype != local.dtype:
+        raise ValueError('inject_fuse: bad shapes')
+    out = torch.empty((rows, C), dtype=local.dtype, device=dev)
+    check(lib().ss_inject_fuse(dt(local), _p(local), ldl, _p(gact), lda, _p(gemb), lde, _p(out), C, B, hl, wl, hg, wg, C, _stream()))
+    return out
+
+
+def bilinear_add(x, y, B, hi, wi, ho, wo):
+    """y [B*ho*wo, C] += bilinear(x [B*hi*wi, C])."""
+    _dev(x)
+    rows, C, ldx = _mat(x, 'x')
+    ro, Co, ldy = _mat(y, 'y')
+    if rows != B * hi * wi or ro != B * ho * wo or Co != C or x.dtype != y.dtype:
+        raise ValueError('bilinear_add: bad shapes')
+    check(lib().ss_bilinear_add(dt(x), _p(x), ldx, _p(y), ldy, B, hi, wi, ho, wo, C, _stream()))
+    return y

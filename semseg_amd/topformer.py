@@ -1,0 +1,350 @@
+"""TopFormer token pyramid + SimpleHead + classifier on the MI355X kernels — inference path (BASELINE configs[3]).
+
+Mirrors the public surface of the reference: ``TopFormerBackBone(config_alias, input_channels, injection_type)(x) ->
+OrderedDict[stage -> Tensor]`` with ``.injection_configs`` / ``.net.stage_names`` (modules/topformer.py:1120-1395), and
+``TopFormerModel(num_classes, config_alias, input_channels, injection_type, fusion, head_cfg)(x) -> logits [B, nc, H, W]``
+(core/models.py:16-115), with the reference's ``state_dict`` keys (checked against manifests dumped from the reference:
+tests/golden/topformer_*_manifest.json).  The module tree below only HOLDS parameters under those names; the forward is one
+flat launch sequence over channels-last token matrices:
+
+* every conv-BN(-act) block (modules/blocks.py:17-198, BN in eval mode) is ONE GEMM / depthwise launch with BN folded into
+  weight and bias and the activation in the epilogue; the asymmetric AutoPadding (modules/layers.py:146-164) is honoured by the
+  im2col / depthwise kernels;
+* attention (modules/topformer.py:411-427, un-scaled QK^T, key_dim 16, value dim 32) runs on the MiT flash kernel with q/k
+  zero-padded to the value head dim (zero columns do not change the dot products) — no [tokens x tokens] matrix;
+* PyramidPoolAgg writes channel slices of one concat buffer; InjectionDotSum is one fused kernel (both bilinear maps on the
+  fly); the SimpleHead sum is accumulated in place; the 1x1 classifier runs BEFORE the x4 bilinear up-sampling (both linear:
+  16x fewer FLOPs, no 256-channel full-resolution tensor; exact in real arithmetic).
+
+Instantiated quirks kept: injection ``global_act`` uses the backbone activation (ReLU6), the attention
+projection is act -> conv -> BN, the pyramid uses ReLU.  Unlike the reference, construction works more than once per process.
+Training mode (batch-statistic BatchNorm + backward) and the RefinerHead are not on the MI355X path yet: they raise.
+"""
+from collections import OrderedDict
+import torch
+from torch import nn, Tensor
+
+from . import ops
+from .runtime import compute_dtype_for
+
+# [kernel, expand_ratio, base_channels, stride] per block (modules/topformer.py:1121-1378)
+TOPFORMER_CONFIGS = {
+    'T': dict(stages=[[[3, 1, 16, 1], [3, 4, 16, 2], [3, 3, 16, 1]], [[5, 3, 32, 2], [5, 3, 32, 1]], [[3, 3, 64, 2], [3, 3, 64, 1]],
+                      [[5, 6, 96, 2], [5, 6, 96, 1]]], out_channels=[128] * 4),
+    'S': dict(stages=[[[3, 1, 16, 1], [3, 4, 24, 2], [3, 3, 24, 1]], [[5, 3, 48, 2], [5, 3, 48, 1]], [[3, 3, 96, 2], [3, 3, 96, 1]],
+                      [[5, 6, 128, 2], [5, 6, 128, 1], [3, 6, 128, 1]]], out_channels=[192] * 4),
+    'B': dict(stages=[[[3, 1, 16, 1], [3, 4, 32, 2], [3, 3, 32, 1]], [[5, 3, 64, 2], [5, 3, 64, 1]], [[3, 3, 128, 2], [3, 3, 128, 1]],
+                      [[5, 6, 160, 2], [5, 6, 160, 1], [3, 6, 160, 1]]], out_channels=[256] * 4),
+}
+for _c in TOPFORMER_CONFIGS.values():
+    _c.update(num_heads=4, c2t_stride=2, depths=4, key_dim=16, attn_ratios=2, mlp_ratios=2)
+RELU, RELU6 = 2, 3
+
+
+def make_divisible(value, divisor=8, min_value=8):
+    """modules/utils.py make_divisible."""
+    new = max(min_value, int(value + divisor / 2) // divisor * divisor)
+    if new < 0.9 * value:
+        new += divisor
+    return new
+
+
+def auto_pad(k, s):
+    """AutoPadding (modules/layers.py:146-164): total d(k-1) - (s-1), smaller half first."""
+    total = (k - 1) - (s - 1)
+    return total // 2, total - total // 2
+
+
+class ConvUnit(nn.Module):
+    """Parameter container with the naming of modules/blocks.py ConvolutionBlock: net.p_conv.conv (+ net.norm)."""
+
+    def __init__(self, inc, outc, k=1, stride=1, groups=1, bias=False, norm=True, act=0, order='CNA'):
+        super().__init__()
+        p_conv = nn.Sequential()
+        p_conv.add_module('conv', nn.Conv2d(inc, outc, k, stride, 0, groups=groups, bias=bias))
+        self.net = nn.Sequential()
+        self.net.add_module('p_conv', p_conv)
+        if norm:
+            self.net.add_module('norm', nn.BatchNorm2d(inc if order.index('N') < order.index('C') else outc))
+        self.k, self.stride, self.groups, self.act, self.order, self.inc, self.outc = k, stride, groups, act, order, inc, outc
+
+    def folded(self):
+        """-> (weight [O, I/g, k, k] fp32, bias [O] fp32) with the eval-mode BatchNorm folded in (norm after conv)."""
+        conv = self.net.p_conv.conv
+        w = conv.weight.detach().float()
+        b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+        if hasattr(self.net, 'norm'):
+            bn = self.net.norm
+            scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+            shift = bn.bias.detach() - bn.running_mean * scale
+            w = w * scale.view(-1, 1, 1, 1)
+            b = b * scale + shift
+        return w.contiguous(), b.contiguous()
+
+
+def _container(**children):
+    m = nn.Module()
+    for k, v in children.items():
+        m.add_module(k, v)
+    return m
+
+
+class InvertedResidual(nn.Module):
+    def __init__(self, inc, outc, kernel_size, stride, expand_ratio):
+        super().__init__()
+        hidden = int(round(inc * expand_ratio))
+        self.residual_connect = stride == 1 and inc == outc
+        self.net = nn.Sequential()
+        if expand_ratio != 1:
+            self.net.add_module('conv_in', ConvUnit(inc, hidden, 1, act=RELU))
+        self.net.add_module('conv_dw', ConvUnit(hidden, hidden, kernel_size, stride, groups=hidden, act=RELU))
+        self.net.add_module('conv_out', ConvUnit(hidden, outc, 1))
+        self.out_channels = outc
+
+
+class TopFormerModule(nn.Module):
+    def __init__(self, cfg, input_channels, injection_type):
+        super().__init__()
+        if injection_type != 'dot_sum':
+            raise NotImplementedError("TopFormer on the MI355X path implements injection_type='dot_sum' (what train.py / predict.py use)")
+        self.injection_type = injection_type
+        # token pyramid
+        stem = ConvUnit(input_channels, 16, 3, 2, act=RELU)
+        staging, feats, cin = nn.Sequential(), OrderedDict(), 16
+        for si, stage in enumerate(cfg['stages']):
+            seq = nn.Sequential()
+            for bi, (k, e, base, s) in enumerate(stage):
+                outc = make_divisible(base * 1.0, 8, 8)
+                seq.add_module(f'resblock_{bi + 1}', InvertedResidual(cin, outc, k, s, e))
+                cin = outc
+            staging.add_module(f'stage_{si + 1}', seq)
+            feats[f'stage_{si + 1}'] = cin
+        tpm_net = nn.Sequential()
+        tpm_net.add_module('stem', stem)
+        tpm_net.add_module('staging_module', staging)
+        self.tpm = _container(net=tpm_net)
+        self.tpm.out_channels = feats
+        self.stage_names = tuple(feats.keys())
+        self.channel_splits = tuple(feats.values())
+        self.embed_dim = sum(self.channel_splits)
+        self.injection_configs = {k: {'inc': feats[k], 'outc': n} for k, n in zip(self.stage_names, cfg['out_channels'])}
+        self.c2t_stride = cfg['c2t_stride']
+        # semantics extractor
+        dim, kd, nh = self.embed_dim, cfg['key_dim'], cfg['num_heads']
+        self.key_dim, self.num_heads, self.d = kd, nh, int(cfg['attn_ratios'] * kd)
+        if self.d not in (32, 64) or kd > self.d:
+            raise NotImplementedError('TopFormer attention on the MI355X path needs value head dim 32 or 64 and key_dim <= it')
+        hidden = int(dim * cfg['mlp_ratios'])
+        seq = nn.Sequential()
+        for i in range(cfg['depths']):
+            attn = _container(multi_branch=_container(branch_q=ConvUnit(dim, nh * kd), branch_k=ConvUnit(dim, nh * kd),
+                                                      branch_v=ConvUnit(dim, nh * self.d)),
+                              projection=ConvUnit(nh * self.d, dim, act=RELU6, order='ACN'))
+            mlp_net = nn.Sequential()
+            mlp_net.add_module('preconv', ConvUnit(dim, hidden))
+            mlp_net.add_module('dwconv', ConvUnit(hidden, hidden, 3, 1, groups=hidden, bias=True, act=RELU6))
+            mlp_net.add_module('postconv', ConvUnit(hidden, dim))
+            seq.add_module(f'extractor_{i + 1}', _container(attn=attn, mlp=_container(net=mlp_net)))
+        self.trans = _container(transformer_sequence=seq)
+        # injection
+        self.post_stages = nn.Sequential()
+        for k, c in self.injection_configs.items():
+            self.post_stages.add_module(k, _container(local_embedding=ConvUnit(c['inc'], c['outc']), global_embedding=ConvUnit(c['inc'], c['outc']),
+                                                      global_act=ConvUnit(c['inc'], c['outc'], act=RELU6)))
+
+
+def _w2(w, T):
+    """folded conv weight [O, I, 1, 1] -> GEMM operand [O, I] in the compute dtype."""
+    w = w.reshape(w.shape[0], -1).contiguous()
+    return w if T == torch.float32 else ops.cast(w, T)
+
+
+class _Plan:
+    """Folded, repacked inference weights of one TopFormerModel for one compute dtype (rebuilt when parameters change)."""
+
+    def __init__(self, model, T):
+        net = model.backbone.net
+        self.T = T
+        u = net.tpm.net.stem
+        w, b = u.folded()
+        self.stem = (ops.pack_conv_weight(w, T, transposed=False)[0], b)
+        self.blocks = []
+        for stage in net.tpm.net.staging_module:
+            for blk in stage:
+                ent = {'res': blk.residual_connect}
+                if hasattr(blk.net, 'conv_in'):
+                    w, b = blk.net.conv_in.folded()
+                    ent['in'] = (_w2(w, T), b)
+                dw = blk.net.conv_dw
+                w, b = dw.folded()
+                C = w.shape[0]
+                ent['dw'] = (ops.transpose_cast(w.reshape(C, dw.k * dw.k).contiguous(), torch.float32), b, dw.k, dw.stride)
+                w, b = blk.net.conv_out.folded()
+                ent['out'] = (_w2(w, T), b)
+                ent['last'] = blk is stage[-1]
+                self.blocks.append(ent)
+        nh, kd, d = net.num_heads, net.key_dim, net.d
+        self.ext = []
+        for ex in net.trans.transformer_sequence:
+            mb = ex.attn.multi_branch
+
+            def padded(unit):                                   # [nh*kd, dim] -> [nh*d, dim] with zero rows (and zero bias) per head
+                w, b = unit.folded()
+                wp = torch.zeros((nh, d, w.shape[1]), device=w.device)
+                bp = torch.zeros((nh, d), device=w.device)
+                wp[:, :kd] = w.reshape(nh, kd, -1)
+                bp[:, :kd] = b.reshape(nh, kd)
+                return wp.reshape(nh * d, -1), bp.reshape(-1)
+            wq, bq = padded(mb.branch_q)
+            wk, bk = padded(mb.branch_k)
+            wv, bv = mb.branch_v.folded()
+            wkv, bkv = torch.cat([wk, wv.reshape(nh * d, -1)]), torch.cat([bk, bv])
+            wpj, bpj = ex.attn.projection.folded()
+            wpre, bpre = ex.mlp.net.preconv.folded()
+            wdw, bdw = ex.mlp.net.dwconv.folded()
+            wpo, bpo = ex.mlp.net.postconv.folded()
+            Ch = wdw.shape[0]
+            self.ext.append(dict(q=(_w2(wq, T), bq.contiguous()), kv=(_w2(wkv, T), bkv.contiguous()), proj=(_w2(wpj, T), bpj),
+                                 pre=(_w2(wpre, T), bpre), dw=(ops.transpose_cast(wdw.reshape(Ch, 9).contiguous(), torch.float32), bdw),
+                                 post=(_w2(wpo, T), bpo)))
+        self.inj = OrderedDict()
+        for name, m in net.post_stages.named_children():
+            self.inj[name] = {k: (lambda wb: (_w2(wb[0], T), wb[1]))(getattr(m, k).folded()) for k in ('local_embedding', 'global_embedding', 'global_act')}
+        if model.head is not None:
+            w, b = model.head.conv.folded()
+            self.head = (_w2(w, T), b)
+            wc = model.classifier.net.p_conv.conv.weight.detach().float().reshape(model.out_channels, -1)
+            ncp = (model.out_channels + 7) // 8 * 8
+            wcp = torch.zeros((ncp, wc.shape[1]), device=wc.device)
+            wcp[:model.out_channels] = wc
+            self.cls = _w2(wcp, T)
+
+
+class TopFormerBackBone(nn.Module):
+    def __init__(self, config_alias: str = 'S', input_channels: int = 3, injection_type: str = 'dot_sum'):
+        super().__init__()
+        self.net = TopFormerModule(TOPFORMER_CONFIGS[config_alias], input_channels, injection_type)
+        self.injection_configs = self.net.injection_configs
+        self._plans = {}
+
+    def train(self, mode: bool = True):
+        self._plans = {}
+        return super().train(mode)
+
+    def _run(self, x, plan):
+        """x: fp32 NCHW image -> OrderedDict stage -> (tokens [B*h*w, C], h, w)."""
+        net, T = self.net, plan.T
+        B, cin, H, W = x.shape
+        t = ops.nchw_to_nhwc(x.contiguous().float(), T)
+        pt, _ = auto_pad(3, 2)
+        h, w = H // 2, W // 2
+        col = ops.im2col_ex(t, B, H, W, cin, 3, 2, pt, pt, h, w)
+        y = ops.gemm_nt(col, plan.stem[0], bias=plan.stem[1], act=RELU)
+        pyr = OrderedDict()
+        names = iter(net.stage_names)
+        for ent in plan.blocks:
+            z = ops.gemm_nt(y, ent['in'][0], bias=ent['in'][1], act=RELU) if 'in' in ent else y
+            wdw, bdw, k, s = ent['dw']
+            p0, _ = auto_pad(k, s)
+            ho, wo = h // s, w // s
+            z = ops.dwconvk_fwd(z, wdw, bdw, B, h, w, k, s, p0, p0, ho, wo, act=RELU)
+            y = ops.gemm_nt(z, ent['out'][0], bias=ent['out'][1], res=y if ent['res'] else None)
+            h, w = ho, wo
+            if ent['last']:
+                pyr[next(names)] = (y, h, w)
+        # pyramid pool aggregation -> [B*hg*wg, embed_dim]
+        hg, wg = h // net.c2t_stride, w // net.c2t_stride
+        if any(ph % hg or pw % wg or ph // hg != pw // wg for _, ph, pw in pyr.values()):
+            raise ValueError(f'TopFormer: input {H}x{W} must be a multiple of 64 (adaptive pooling windows must be exact)')
+        tok = torch.empty((B * hg * wg, net.embed_dim), dtype=T, device=x.device)
+        off = 0
+        for (f, ph, pw), c in zip(pyr.values(), net.channel_splits):
+            ops.avgpool(f, B, ph, pw, ph // hg, out=tok[:, off:off + c])
+            off += c
+        n = hg * wg
+        for e in plan.ext:
+            q = ops.gemm_nt(tok, e['q'][0], bias=e['q'][1])
+            kv = ops.gemm_nt(tok, e['kv'][0], bias=e['kv'][1])
+            ao, _ = ops.mit_attn_fwd(q, kv, B, n, n, net.num_heads, scale=1.0)
+            tok = ops.gemm_nt(ops.act(ao, RELU6), e['proj'][0], bias=e['proj'][1], res=tok)
+            z = ops.gemm_nt(tok, e['pre'][0], bias=e['pre'][1])
+            z = ops.dwconvk_fwd(z, e['dw'][0], e['dw'][1], B, hg, wg, 3, 1, 1, 1, hg, wg, act=RELU6)
+            tok = ops.gemm_nt(z, e['post'][0], bias=e['post'][1], res=tok)
+        out, off = OrderedDict(), 0
+        for name, c in zip(net.stage_names, net.channel_splits):
+            f, ph, pw = pyr[name]
+            wts, xg = plan.inj[name], tok[:, off:off + c]
+            off += c
+            local = ops.gemm_nt(f, wts['local_embedding'][0], bias=wts['local_embedding'][1])
+            ga = ops.gemm_nt(xg, wts['global_act'][0], bias=wts['global_act'][1], act=RELU6)
+            ge = ops.gemm_nt(xg, wts['global_embedding'][0], bias=wts['global_embedding'][1])
+            out[name] = (ops.inject_fuse(local, ga, ge, B, ph, pw, hg, wg), ph, pw)
+        return out
+
+    def _plan_for(self, model, x):
+        if self.training:
+            raise NotImplementedError('TopFormer on the MI355X path is inference-only (call .eval()); training-mode BatchNorm is not built yet')
+        key = (compute_dtype_for(x), model.head is not None)
+        if key not in self._plans:
+            with torch.no_grad():
+                self._plans[key] = _Plan(model, key[0])
+        return self._plans[key]
+
+    def forward(self, x: Tensor):
+        holder = _BackboneOnly(self)
+        with torch.no_grad():
+            feats = self._run(x, self._plan_for(holder, x))
+        b = x.shape[0]
+        return OrderedDict((k, t.view(b, h, w, -1).permute(0, 3, 1, 2)) for k, (t, h, w) in feats.items())
+
+
+class _BackboneOnly:
+    head = None
+
+    def __init__(self, backbone):
+        self.backbone = backbone
+
+
+class SimpleHead(nn.Module):
+    """modules/heads.py:120-170 (fusion 'sum'): parameter container for the fused conv-BN-ReLU6."""
+
+    def __init__(self, in_channels, embedding_dim):
+        super().__init__()
+        self.conv = ConvUnit(in_channels, embedding_dim, act=RELU6)
+
+
+class TopFormerModel(nn.Module):
+    def __init__(self, num_classes: int, config_alias: str = 'B', input_channels: int = 3, injection_type: str = 'dot_sum',
+                 fusion: str = 'sum', head_cfg=frozenset({'alias': 'simple'}.items())):
+        super().__init__()
+        assert isinstance(fusion, str) and fusion.lower() in {'concat', 'sum'}, f"Unknown fusion: {fusion}\nSupported fusion modes are: {{'concat', 'sum'}}"
+        head_cfg = dict(head_cfg)
+        if head_cfg.get('alias') != 'simple' or fusion.lower() != 'sum':
+            raise NotImplementedError("TopFormerModel on the MI355X path implements head 'simple' with fusion 'sum' this round "
+                                      "(RefinerHead / concat fusion: next)")
+        self.out_channels = num_classes
+        self.backbone = TopFormerBackBone(config_alias, input_channels, injection_type)
+        inc = tuple(c['outc'] for c in self.backbone.injection_configs.values())[0]
+        self.head = SimpleHead(inc, inc)
+        self.classifier = ConvUnit(inc, num_classes, norm=False)
+
+    def train(self, mode: bool = True):
+        self.backbone._plans = {}
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.backbone._plans = {}
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def forward(self, x: Tensor) -> Tensor:
+        b, c, H, W = x.shape
+        with torch.no_grad():
+            plan = self.backbone._plan_for(self, x)
+            feats = list(self.backbone._run(x, plan).values())
+            acc, h4, w4 = feats[0]
+            for t, h, w in feats[1:]:
+                ops.bilinear_add(t, acc, b, h, w, h4, w4)
+            y = ops.gemm_nt(acc, plan.head[0], bias=plan.head[1], act=RELU6)
+            logits4 = ops.gemm_nt(y, plan.cls)                                  # [B*h4*w4, round8(nc)], classifier before the up-sampling
+            full = ops.bilinear_fwd(logits4, b, h4, w4, H, W)
+        return full.view(b, H, W, -1)[..., :self.out_channels].permute(0, 3, 1, 2)

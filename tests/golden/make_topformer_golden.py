@@ -1,0 +1,43 @@
+"""Golden vectors / manifests for TopFormerModel from the REFERENCE (imported from /root/reference, CPU fp32, eval mode).
+The reference's TopFormer can be constructed once per process, so this script builds ONE model per run:
+
+    cd /root/repo && for a in B:simple B:refiner S:simple T:simple; do PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_topformer_golden.py $a; done
+"""
+import json
+import os
+import sys
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(1, '/root/reference')
+sys.dont_write_bytecode = True
+from semseg_amd.detinit import det_fill_, det_input  # noqa: E402
+from core.models import TopFormerModel  # noqa: E402  (reference)
+from modules.topformer import TopFormerBackBone  # noqa: E402  (reference)
+
+alias, head = sys.argv[1].split(':')
+cfgs = getattr(TopFormerBackBone, '_TopFormerBackBone__available_configs')
+tables = {}
+for a, c in cfgs.items():
+    tables[a] = {'stages': [[[b['kernel_size'], b['expand_ratio'], b['base_channels'], b['stride']] for b in st.values()]
+                            for st in c['stage_configs'].values()],
+                 'out_channels': list(c['out_channels'].values()), 'num_heads': c['num_heads'], 'c2t_stride': c['c2t_stride'],
+                 'depths': c['depths'], 'key_dim': c['key_dim'], 'attn_ratios': c['attn_ratios'], 'mlp_ratios': c['mlp_ratios']}
+json.dump(tables, open(os.path.join(HERE, 'topformer_configs.json'), 'w'), indent=1)
+
+net = det_fill_(TopFormerModel(6, alias, 3, 'dot_sum', 'sum', frozenset({'alias': head}.items()))).eval()
+manifest = {k: list(v.shape) for k, v in net.state_dict().items()}
+json.dump(manifest, open(os.path.join(HERE, f'topformer_{alias}_{head}_manifest.json'), 'w'), indent=0)
+x = det_input('top.x', (2, 3, 128, 192))
+with torch.no_grad():
+    feats = net.backbone(x)
+    out = net(x)
+save = {'logits': out.numpy()}
+for k, v in feats.items():                      # the two coarsest injected maps (the fine ones would be megabytes)
+    if k in ('stage_3', 'stage_4'):
+        save['feat.' + k] = v.numpy()
+np.savez_compressed(os.path.join(HERE, f'topformer_{alias}_{head}.npz'), **save)
+print(alias, head, 'logits', tuple(out.shape), 'params', sum(p.numel() for p in net.parameters()), 'keys', len(manifest))
