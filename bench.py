@@ -32,7 +32,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='mit_lawin', choices=['mit_lawin', 'dnet'],
+    ap.add_argument('--workload', default='mit_lawin', choices=['mit_lawin', 'dnet', 'topformer'],
                     help="mit_lawin = BASELINE configs[1] (the headline); dnet = configs[2] per-GPU step (DNet-T, embed 256, batch 8, Dice loss)")
     ap.add_argument('--variant', default='B2')
     ap.add_argument('--embed', type=int, default=512)
@@ -217,6 +217,54 @@ def cpu_baseline():
             'sample': 'configs[0]: MiT-B0 + Lawin(256, 6 cls) fp32, batch 2x3x512x512, fwd + OHEM-CE + bwd, median of 3 steps after 1 warm-up'}
 
 
+def topformer_inference(a, world, rank, dev):
+    """configs[3]: TopFormer-B (SimpleHead) inference images/sec on 2048x2048 tiles, replicas only (no collective on the data path)."""
+    from semseg_amd.topformer import TopFormerModel
+    from semseg_amd.detinit import det_fill_
+    from semseg_amd.runtime import set_compute_dtype
+    from semseg_amd import _lib
+    set_compute_dtype(torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
+    size = a.size if a.size != 1024 else 2048
+    batch = a.batch if a.batch != 16 else 4
+    net = det_fill_(TopFormerModel(6, 'B')).to(dev).eval()
+    x, _ = synthetic_batch(batch, size, rank, dev)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        net(x)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = net(x)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    _lib.TRACE = []
+    net(x)
+    trace, _lib.TRACE = _lib.TRACE, None
+    if rank == 0:
+        table = kernel_table(trace)
+        res = {'metric': 'inference images/sec @2048x2048 (TopFormer-B)', 'value': batch * world * a.steps / dt, 'unit': 'images/s', 'n_gpus': world,
+               'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+               'config': {'workload': f'configs[3]: TopFormer-B + SimpleHead inference, {size}x{size}', 'per_gpu_batch': batch,
+                          'global_batch': batch * world, 'parallelism': f'replicas x{world}'},
+               'roofline': roofline_from_table(table)}
+        if a.table:
+            tot = sum(t['ms'] for t in table.values())
+            for name, t in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
+                print(f"{name:28s} {t['calls']:5d} calls {t['ms']:9.2f} ms {100 * t['ms'] / tot:5.1f}%", file=sys.stderr)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -241,6 +289,8 @@ def main():
 
     T = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     set_compute_dtype(T)
+    if a.workload == 'topformer':
+        return topformer_inference(a, world, rank, dev)
     if a.workload == 'dnet':
         from semseg_amd.decoder import DNet
         from semseg_amd.loss import DiceLoss
