@@ -242,7 +242,7 @@ def topformer_inference(a, world, rank, dev):
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     _lib.TRACE = []
@@ -267,6 +267,9 @@ def topformer_inference(a, world, rank, dev):
 
 def main():
     a = parse()
+    if os.environ.get('SEMSEG_BENCH_DEBUG'):                      # dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['SEMSEG_BENCH_DEBUG']), exit=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -274,10 +277,15 @@ def main():
         raise SystemExit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch N > 1 through torch.distributed.run')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    local = local % torch.cuda.device_count()       # rehearsal of N ranks on fewer GPUs (SEMSEG_BENCH_BACKEND=gloo); one rank per GPU otherwise
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('SEMSEG_BENCH_BACKEND', 'nccl')            # nccl == RCCL over xGMI on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from semseg_amd.model import SegFormerLawin
     from semseg_amd.loss import OhemCrossEntropyLoss
@@ -330,7 +338,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     cm = met.compute()                                           # int64 confusion-matrix all-reduce (C2)

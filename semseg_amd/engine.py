@@ -24,6 +24,21 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _host_staged(t):
+    """gloo cannot move device memory between processes that share a GPU: stage through the host for that backend
+    (rehearsals of the N-rank path on one box; RCCL takes device pointers directly)."""
+    return t.is_cuda and dist.get_backend() == 'gloo'
+
+
+def all_reduce_sum(t, async_op=False):
+    if _host_staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
 class FlatParams:
     def __init__(self, model, align=64):
         params = [p for p in model.parameters() if p.requires_grad]
@@ -97,9 +112,11 @@ class GradReducer:
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+                work = all_reduce_sum(view, async_op=True)
         else:
-            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            work = all_reduce_sum(view, async_op=True)
+        if work is not None:
+            self.works.append(work)
 
     def wait(self):
         """Launch whatever has not been launched (unused parameters, overlap off), join, re-arm.  -> grad_scale."""
@@ -121,7 +138,12 @@ def broadcast_module_state(model, src=0):
         return
     with torch.no_grad():
         for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, src)
+            if _host_staged(t):
+                h = t.data.cpu()
+                dist.broadcast(h, src)
+                t.data.copy_(h)
+            else:
+                dist.broadcast(t.data, src)
 
 
 class AdaBound:

@@ -77,8 +77,9 @@ class SegmentationMetrics(nn.Module):
     def synced_confmat(self):
         cm = self.confmat
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            from .engine import all_reduce_sum
             cm = cm.clone()
-            torch.distributed.all_reduce(cm, op=torch.distributed.ReduceOp.SUM)
+            all_reduce_sum(cm)
         return cm
 
     def compute(self):
