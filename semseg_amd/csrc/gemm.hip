@@ -257,12 +257,13 @@ extern "C" int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, co
     SS_CHECK(!res || ldr >= N, "ss_gemm_nt: bad ldr");
     SS_CHECK(!rowscale || rows_per_scale > 0, "ss_gemm_nt: rows_per_scale must be > 0");
     SS_CHECK(cdiv(M, 128) * cdiv(N, 64) < 2147483647LL, "ss_gemm_nt: too many tiles");
-    if (dtype == SS_BF16 && !out_f32 && ss_fast_nt_ok(A, lda, B, ldb, C, ldc, M, N, K, res, ldr, bias)) {
+    if (dtype == SS_BF16 && !out_f32) {
         FastGemm f{};
         f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = C; f.M = M; f.N = (int)N; f.K = K; f.lda = lda; f.ldb = ldb; f.ldc = ldc;
         f.bias = bias; f.res = (const bf16*)res; f.ldr = ldr; f.rowscale = rowscale; f.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
         f.act = act; f.k_per_split = K;
-        return ss_fast_nt_launch(f, stream);
+        if (ss_skinny_nt_ok(f)) return ss_skinny_nt_launch(f, stream);
+        if (ss_fast_nt_ok(A, lda, B, ldb, C, ldc, M, N, K, res, ldr, bias)) return ss_fast_nt_launch(f, stream);
     }
     GemmParams p{};
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = (int)N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -316,7 +317,13 @@ extern "C" int ss_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, 
     p.vecA = aligned16(A) && lda % vec == 0 && M % vec == 0;
     p.vecB = aligned16(B) && ldb % vec == 0 && N % vec == 0;
     dim3 block(256);
-    if (dtype == SS_BF16 && ss_fast_tn_ok(A, lda, B, ldb, M, N)) {
+    if (dtype == SS_BF16 && ss_skinny_tn_ok(B, ldb, M, N)) {
+        FastGemm f{};
+        f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = workspace; f.M = M; f.N = (int)N; f.K = R; f.lda = lda; f.ldb = ldb; f.ldc = N;
+        f.k_per_split = rps;
+        int rc = ss_skinny_tn_launch(f, ns, stream);
+        if (rc) return rc;
+    } else if (dtype == SS_BF16 && ss_fast_tn_ok(A, lda, B, ldb, M, N)) {
         FastGemm f{};
         f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = workspace; f.M = M; f.N = (int)N; f.K = R; f.lda = lda; f.ldb = ldb; f.ldc = N;
         f.k_per_split = rps;

@@ -126,33 +126,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(FastGemm p) {
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int ml = wm * 64 + a * 32 + li;
-        const int64_t m = m0 + ml;
-        float rs = 1.f;
-        if (p.rowscale && m < p.M) rs = p.rowscale[m / p.rows_per_scale];
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = wn * (BN / 2) + b * 32 + 8 * g + 4 * lh;
-                floatx4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias && n0 + nl < p.N) bv = *(const floatx4*)(p.bias + n0 + nl);
-                bf16x4* cell = (bf16x4*)(smem + ml * EP + nl * 2);
-                bf16x4 rv = {0, 0, 0, 0};
-                if (p.res) rv = *cell;
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[a][b][4 * g + e] + bv[e];
-                    v = apply_act(v, p.act);
-                    v = v * rs + (float)rv[e];
-                    o[e] = (bf16)v;
-                }
-                *cell = o;
-            }
-    }
+    nt_epilogue_dispatch<2, TN>(acc, p, smem, EP, m0, n0, wm * 64, wn * (BN / 2), li, lh);
     __syncthreads();
 #pragma unroll
     for (int ps = 0; ps < BM / RPP; ++ps) {
@@ -274,7 +248,14 @@ bool ss_fast_nt_ok(const void* A, int64_t lda, const void* B, int64_t ldb, const
     return cdiv(M, 128) * cdiv(N, 64) < (1LL << 30);
 }
 
+static int big_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SS_GEMM_BIG"); on = !(e && e[0] == '0'); }
+    return on;
+}
+
 int ss_fast_nt_launch(FastGemm p, hipStream_t st) {
+    if (big_enabled() && ss_big_nt_ok(p)) return ss_big_nt_launch(p, st);
     const bool narrow = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 1024);
     if (narrow) {
         p.ntn = (int)cdiv(p.N, 64);

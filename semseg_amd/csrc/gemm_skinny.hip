@@ -1,0 +1,125 @@
+// Skinny bf16 GEMMs of the 6-class classifier: one side of the product is <= 8 wide, so there is nothing for
+// the MFMA tiles to chew on and the launch is bound by streaming the wide operand through HBM once.
+//
+//   gemm_nt_smallk_kernel : C[M,N] = A[M,K] . B[N,K]^T (+ bias), K <= 8      (input gradient dX = dY . W: writes M x N)
+//   gemm_tn_smallm_kernel : slab[z][M,N] = sum_r A[r,M]^T . B[r,N], M <= 8   (weight gradient dW = dY^T . X: reads R x N)
+//
+// Both: a lane owns 8 consecutive columns of the wide side (one 16-byte access per row), a wave walks rows; the <= 8 values of
+// the narrow operand's row are fetched by 8 lanes each for 8 rows at a time and broadcast with v_readlane.
+#include "common.h"
+#include "gemm_fast.h"
+
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+__global__ __launch_bounds__(256) void gemm_nt_smallk_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
+                                                             int64_t ldb, bf16* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
+                                                             const float* __restrict__ bias) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = (blockIdx.y * 64 + lane) * 8;
+    const bool active = col < N;
+    float w[8][8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bv[j] = (active && bias) ? bias[col + j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k][j] = (active && k < K) ? (float)B[(int64_t)(col + j) * ldb + k] : 0.f;
+    }
+    const int64_t groups = cdiv(M, 8);
+    const int rr = lane >> 3, kk = lane & 7;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < groups; g += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = g * 8;
+        const float av = (r0 + rr < M && kk < K) ? (float)A[(r0 + rr) * lda + kk] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (r0 + i >= M) break;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = bv[j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float a = lane_bcast(av, i * 8 + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(a, w[k][j], acc[j]);
+            }
+            if (active) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+                *(bf16x8*)(C + (r0 + i) * ldc + col) = o;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_smallm_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
+                                                             int64_t ldb, float* __restrict__ slabs, int M, int N, int64_t R,
+                                                             int64_t rps) {
+    __shared__ float red[4][64][65];                   // [wave][m*8+j][lane] (+1: the gather below walks the middle index)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = (blockIdx.y * 64 + lane) * 8;
+    const bool active = col < N;
+    const int64_t rbeg = (int64_t)blockIdx.x * rps;
+    const int64_t rend = rbeg + rps < R ? rbeg + rps : R;
+    float acc[8][8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[m][j] = 0.f;
+    const int rr = lane >> 3, mm = lane & 7;
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t r0 = rbeg + wave * 8; r0 < rend; r0 += 32) {
+        const float av = (r0 + rr < rend && mm < M) ? (float)A[(r0 + rr) * lda + mm] : 0.f;
+        bf16x8 b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = (active && r0 + i < rend) ? *(const bf16x8*)(B + (r0 + i) * ldb + col) : zero;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float bf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bf[j] = (float)b[i][j];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float a = lane_bcast(av, i * 8 + m);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[m][j] = fmaf(a, bf[j], acc[m][j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][m * 8 + j][lane] = acc[m][j];
+    __syncthreads();
+    float* slab = slabs + (int64_t)blockIdx.x * M * N;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int mj = e & 63, ln = e >> 6;                // consecutive threads -> consecutive j, m of one lane's 8 columns
+        const int m = mj >> 3, j = mj & 7;
+        const int c = (blockIdx.y * 64 + ln) * 8 + j;
+        if (m < M && c < N) slab[(int64_t)m * N + c] = ((red[0][mj][ln] + red[1][mj][ln]) + red[2][mj][ln]) + red[3][mj][ln];
+    }
+}
+
+bool ss_skinny_nt_ok(const FastGemm& p) {
+    return p.K <= 8 && p.N % 8 == 0 && p.ldc % 8 == 0 && aligned16(p.C) && !p.res && !p.rowscale && p.act == 0;
+}
+
+int ss_skinny_nt_launch(const FastGemm& p, hipStream_t st) {
+    const int64_t need = cdiv(cdiv(p.M, 8), 4);
+    dim3 grid((unsigned)(need < 4096 ? need : 4096), (unsigned)cdiv(p.N, 512));
+    hipLaunchKernelGGL(gemm_nt_smallk_kernel, grid, dim3(256), 0, st, p.A, p.lda, p.B, p.ldb, (bf16*)p.C, p.ldc, p.M, p.N, (int)p.K, p.bias);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+bool ss_skinny_tn_ok(const void* B, int64_t ldb, int64_t M, int64_t N) {
+    return M <= 8 && N % 8 == 0 && ldb % 8 == 0 && aligned16(B);
+}
+
+int ss_skinny_tn_launch(const FastGemm& p, int nsplit, hipStream_t st) {
+    dim3 grid((unsigned)nsplit, (unsigned)cdiv(p.N, 512));
+    hipLaunchKernelGGL(gemm_tn_smallm_kernel, grid, dim3(256), 0, st, p.A, p.lda, p.B, p.ldb, (float*)p.C, (int)p.M, p.N, p.K, p.k_per_split);
+    SS_LAUNCH_CHECK();
+    return 0;
+}

@@ -53,7 +53,8 @@ def test_gemm_nt(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize('M,N,K', [(1000, 64, 64), (777, 128, 128), (4099, 320, 320), (513, 512, 560), (260, 1280, 320), (300, 48 + 512, 512),
-                                   (2050, 256, 2560), (129, 576, 152), (640, 8, 64)])
+                                   (2050, 256, 2560), (129, 576, 152), (640, 8, 64), (1003, 512, 6), (77, 1032, 8),
+                                   (65536 + 77, 256, 256), (33000, 512, 320), (17000, 1024, 576)])   # 256 x 256 tile kernel
 def test_gemm_nt_bf16_fast_path(ops, M, N, K):
     """shapes that take the 128 x {64,128} x 64 bf16 kernels: ragged M, K tails (K % 64 != 0), N tails, bias + GELU + DropPath row
     scale + residual in the epilogue, and writes into a channel slice of a wider buffer."""
@@ -74,7 +75,8 @@ def test_gemm_nt_bf16_fast_path(ops, M, N, K):
     assert rel(out3, big[:, 8:8 + K].float().cpu() @ q(b, dtype).t()) < 1e-2
 
 
-@pytest.mark.parametrize('R,M,N', [(5000, 64, 64), (4097, 320, 1280), (9000, 512, 48 + 512), (1024, 128, 2048), (70, 8, 16), (3000, 1152, 320)])
+@pytest.mark.parametrize('R,M,N', [(5000, 64, 64), (4097, 320, 1280), (9000, 512, 48 + 512), (1024, 128, 2048), (70, 8, 16), (3000, 1152, 320),
+                                   (70001, 6, 512), (333, 3, 1032)])
 def test_gemm_tn_bf16_fast_path(ops, R, M, N):
     dtype = torch.bfloat16
     a, b = rnd(R, M), rnd(R, N, seed=1)
