@@ -63,7 +63,7 @@ def entry_work(name, a):
     """-> (bound, algorithmic flops or bytes) for one launch, from its argument list (include/semseg_hip.h order)."""
     if name == 'ss_gemm_nt':
         return 'mfma', 2.0 * a[8] * a[9] * a[10]
-    if name == 'ss_gemm_tn':
+    if name in ('ss_gemm_tn', 'ss_gemm_tn_colsum'):
         return 'mfma', 2.0 * a[7] * a[8] * a[9]
     if name == 'ss_mit_attn_fwd':
         B, N, Nk, h, D = a[5:10]
@@ -139,9 +139,9 @@ def shape_table(trace):
             sz = _sz(a[0])
             key = (name, M, N, K, 'res' if a[12] else '', 'f32out' if a[1] else '')
             byt = (M * K + N * K + M * N * (2 if a[12] else 1)) * sz
-        elif name == 'ss_gemm_tn':
+        elif name in ('ss_gemm_tn', 'ss_gemm_tn_colsum'):
             M, N, K = a[7:10]
-            key = (name, M, N, K, '', '')
+            key = ('ss_gemm_tn', M, N, K, 'cs' if name.endswith('colsum') else '', '')
             byt = (K * M + K * N) * _sz(a[0]) + M * N * 4
         elif name.startswith(('ss_lawin', 'ss_mit_attn', 'ss_bn_', 'ss_dwconv', 'ss_colsum', 'ss_bilinear')):
             key = (name, 0, 0, 0, ' '.join(str(v) for v in a[1:] if isinstance(v, int) and 0 <= v < (1 << 22)), '')

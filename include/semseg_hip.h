@@ -42,6 +42,11 @@ int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, const void* B
 int64_t ss_gemm_tn_workspace(int dtype, int64_t M, int64_t N, int64_t R);
 int ss_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                int64_t M, int64_t N, int64_t R, void* workspace, int64_t ws_bytes, int accumulate, hipStream_t stream);
+/* nn.Linear / 1x1-conv backward in one pass over dY: C as above AND colsum[m] (+)= sum_r A[r, m], the bias gradient
+ * (autograd of modules/segformer.py:14-18,58-62 and the ConvModules of modules/lawin.py).  M and lda multiples of 8. */
+int ss_gemm_tn_colsum(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                      int64_t M, int64_t N, int64_t R, void* workspace, int64_t ws_bytes, int accumulate, float* colsum,
+                      int colsum_accumulate, hipStream_t stream);
 
 /* ---- nn.LayerNorm over C on token layout (modules/segformer.py:19,30,77,83,90,93,145-198). mean/rstd: [rows] fp32. */
 int ss_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,

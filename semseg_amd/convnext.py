@@ -55,7 +55,8 @@ class _PatchConvFn(_ParamFn):
     @staticmethod
     def bwd(P, S, dy, meta):
         B, H, W, Cin, k = meta
-        G = {'bias': ops.colsum(dy)[0], 'weight': ops.unpack_conv_wgrad(ops.gemm_tn(dy, S['col']), dy.shape[1], Cin, k)}
+        gp, db = ops.gemm_tn(dy, S['col'], colsum=True)
+        G = {'bias': db, 'weight': ops.unpack_conv_wgrad(gp, dy.shape[1], Cin, k)}
         dx = None
         if Cin % 8 == 0:                                     # the RGB image needs no gradient
             _, wpt = ops.pack_conv_weight(P['weight'].detach(), dy.dtype, transposed=True)

@@ -9,6 +9,7 @@
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float floatx2;
 typedef __attribute__((ext_vector_type(4))) float floatx4;
 typedef __attribute__((ext_vector_type(8))) float floatx8;

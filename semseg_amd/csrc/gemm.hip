@@ -10,6 +10,7 @@
 // ds_read_b128), with the next tile's global loads in flight under the current tile's MFMAs.
 #include "common.h"
 #include "gemm_fast.h"
+#include "colreduce.h"
 
 __device__ __forceinline__ floatx16 mma32(bf16x8 a, bf16x8 b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -294,22 +295,45 @@ static void tn_plan(int64_t M, int64_t N, int64_t R, int bk, int* nsplit, int64_
     *nsplit = (int)cdiv(R, per);
 }
 
+extern "C" int ss_colsum(int dtype, const void* x, int64_t ld, int64_t rows, int C, int groups, float scale, float* out,
+                         int accumulate, float* workspace, int64_t ws_bytes, hipStream_t stream);
+static const int64_t kColsumWsRows = SS_COLRED_MAX_BLOCKS;             // ss_colsum's partial rows (COLRED_BLOCKS) when the sums cannot be fused
+
 extern "C" int64_t ss_gemm_tn_workspace(int dtype, int64_t M, int64_t N, int64_t R) {
     int ns; int64_t rps;
     tn_plan(M, N, R, dtype == SS_BF16 ? 64 : 32, &ns, &rps);
-    return (int64_t)ns * M * N * (int64_t)sizeof(float);
+    return ((int64_t)ns * M * N + kColsumWsRows * M) * (int64_t)sizeof(float);
 }
+
+static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                        int64_t R, void* workspace, int64_t ws_bytes, int accumulate, float* colsum, int colsum_accumulate,
+                        hipStream_t stream);
 
 extern "C" int ss_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                           int64_t M, int64_t N, int64_t R, void* workspace, int64_t ws_bytes, int accumulate, hipStream_t stream) {
+    return gemm_tn_impl(dtype, A, lda, B, ldb, C, ldc, M, N, R, workspace, ws_bytes, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int ss_gemm_tn_colsum(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                                 int64_t M, int64_t N, int64_t R, void* workspace, int64_t ws_bytes, int accumulate, float* colsum,
+                                 int colsum_accumulate, hipStream_t stream) {
+    SS_CHECK(colsum && M % 8 == 0 && lda % 8 == 0, "ss_gemm_tn_colsum: null colsum, or M / lda not a multiple of 8");
+    return gemm_tn_impl(dtype, A, lda, B, ldb, C, ldc, M, N, R, workspace, ws_bytes, accumulate, colsum, colsum_accumulate, stream);
+}
+
+static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                        int64_t R, void* workspace, int64_t ws_bytes, int accumulate, float* colsum, int colsum_accumulate,
+                        hipStream_t stream) {
     SS_CHECK(A && B && C && workspace, "ss_gemm_tn: null operand");
     SS_CHECK(M > 0 && N > 0 && R > 0 && N < (1 << 30) && M < (1 << 30), "ss_gemm_tn: bad shape");
     SS_CHECK(lda >= M && ldb >= N && ldc >= N, "ss_gemm_tn: leading dimension smaller than the row");
     int ns; int64_t rps;
     int bk = dtype == SS_BF16 ? 64 : 32;
     tn_plan(M, N, R, bk, &ns, &rps);
-    SS_CHECK(ws_bytes >= (int64_t)ns * M * N * 4, "ss_gemm_tn: workspace too small (%lld < %lld)", (long long)ws_bytes,
-             (long long)((int64_t)ns * M * N * 4));
+    const int64_t ws_need = ((int64_t)ns * M * N + kColsumWsRows * M) * 4;
+    SS_CHECK(ws_bytes >= ws_need, "ss_gemm_tn: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)ws_need);
+    float* cs_ws = (float*)workspace + (int64_t)ns * M * N;
+    bool cs_fused = false;
     GemmParams p{};
     p.A = A; p.B = B; p.C = workspace; p.M = M; p.N = (int)N; p.K = R; p.lda = lda; p.ldb = ldb; p.ldc = N;
     p.k_per_split = rps;
@@ -327,6 +351,7 @@ extern "C" int ss_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, 
         FastGemm f{};
         f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = workspace; f.M = M; f.N = (int)N; f.K = R; f.lda = lda; f.ldb = ldb; f.ldc = N;
         f.k_per_split = rps;
+        if (colsum && ns <= kColsumWsRows) { f.colsum_ws = cs_ws; cs_fused = true; }
         int rc = ss_fast_tn_launch(f, ns, stream);
         if (rc) return rc;
     } else if (N <= 64) {
@@ -341,6 +366,16 @@ extern "C" int ss_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, 
         else return ss_fail(-1, "ss_gemm_tn: unsupported dtype %d", dtype);
     }
     SS_LAUNCH_CHECK();
+    if (colsum) {
+        if (cs_fused) {
+            hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(M, 8), 1), dim3(256), 0, stream, (const float*)cs_ws, ns, (int)M, 1.f,
+                               colsum, colsum_accumulate);
+            SS_LAUNCH_CHECK();
+        } else {
+            int rc = ss_colsum(dtype, A, lda, R, (int)M, 1, 1.f, colsum, colsum_accumulate, cs_ws, kColsumWsRows * M * 4, stream);
+            if (rc) return rc;
+        }
+    }
     int64_t n = M * N;
     if (N % 4 == 0 && ldc % 4 == 0 && aligned16(C)) {
         int64_t n4 = n / 4;

@@ -150,9 +150,12 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(FastGemm p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    // one XCD (= one L2) takes ALL output tiles of a run of consecutive splits: the tiles of a split stream the same A / B rows,
+    // and spread over the 8 XCDs every L2 would fetch those rows from the fabric again
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = vid / p.ntiles, wg = vid % p.ntiles;
     const int m0 = (wg / p.ntn) * BM, n0 = (wg % p.ntn) * BN;
-    const int64_t kbeg = (int64_t)blockIdx.z * p.k_per_split;
+    const int64_t kbeg = (int64_t)split * p.k_per_split;
     const int64_t kend = kbeg + p.k_per_split < p.K ? kbeg + p.k_per_split : p.K;
 
     const int arow = tid / CA, ach = tid % CA, brow = tid / CB, bch = tid % CB;
@@ -198,6 +201,8 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(FastGemm p) {
         return f;
     };
 
+    const bool do_cs = p.colsum_ws && n0 == 0;
+    float cs = 0.f;
     if (kbeg < kend) {
         gload(kbeg);
         lstore();
@@ -212,6 +217,15 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(FastGemm p) {
                 for (int a = 0; a < 2; ++a) fa[a] = trfrag(As, PA, ks, wm * 64 + a * 32);
 #pragma unroll
                 for (int b = 0; b < TN; ++b) fb[b] = trfrag(Bs, PB, ks, wn * (BN / 2) + b * 32);
+                if (do_cs) {                              // column sums of A (the bias gradient) ride along in the first n tile:
+                    const bf16x8 f = wn ? fa[1] : fa[0];  // wave (wm, wn) sums its a = wn fragment, 4 x v_dot2_f32_bf16 with (1, 1)
+                    const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16x2 pr = {f[2 * e], f[2 * e + 1]};
+                        cs = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, cs, false);
+                    }
+                }
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -222,8 +236,13 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(FastGemm p) {
             if (more) { lstore(); __syncthreads(); }
         }
     }
+    if (do_cs) {                                          // lane = column (lane & 31) of the A fragment, k split over lane halves
+        const float t = cs + __shfl_xor(cs, 32);
+        const int m = m0 + wm * 64 + wn * 32 + li;
+        if (lh == 0 && m < p.M) p.colsum_ws[(int64_t)split * p.M + m] = t;
+    }
     // fp32 slab: lanes run along n (128-byte segments per register row)
-    float* C = (float*)p.C + (int64_t)blockIdx.z * p.M * p.N;
+    float* C = (float*)p.C + (int64_t)split * p.M * p.N;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -275,10 +294,12 @@ bool ss_fast_tn_ok(const void* A, int64_t lda, const void* B, int64_t ldb, int64
 int ss_fast_tn_launch(FastGemm p, int nsplit, hipStream_t st) {
     if (p.N <= 64) {
         p.ntn = (int)cdiv(p.N, 64);
-        hipLaunchKernelGGL(gemm_tn_bf16_kernel<64>, dim3((unsigned)(p.ntn * cdiv(p.M, 128)), 1, nsplit), dim3(256), 0, st, p);
+        p.ntiles = (int)(p.ntn * cdiv(p.M, 128));
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel<64>, dim3((unsigned)(p.ntiles * nsplit)), dim3(256), 0, st, p);
     } else {
         p.ntn = (int)cdiv(p.N, 128);
-        hipLaunchKernelGGL(gemm_tn_bf16_kernel<128>, dim3((unsigned)(p.ntn * cdiv(p.M, 128)), 1, nsplit), dim3(256), 0, st, p);
+        p.ntiles = (int)(p.ntn * cdiv(p.M, 128));
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel<128>, dim3((unsigned)(p.ntiles * nsplit)), dim3(256), 0, st, p);
     }
     SS_LAUNCH_CHECK();
     return 0;

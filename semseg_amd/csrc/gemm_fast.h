@@ -8,9 +8,10 @@ struct FastGemm {
     int64_t lda, ldb, ldc;
     const float* bias; const bf16* res; int64_t ldr;
     const float* rowscale; int64_t rows_per_scale;
-    int act, ntn;
+    int act, ntn, ntiles;
     int64_t k_per_split;
     int dbg;
+    float* colsum_ws;                       // TN: per-split column sums of A, [nsplit][M] (or null)
 };
 bool ss_fast_nt_ok(const void* A, int64_t lda, const void* B, int64_t ldb, const void* C, int64_t ldc, int64_t M, int64_t N,
                    int64_t K, const void* res, int64_t ldr, const float* bias);

@@ -126,8 +126,7 @@ def head_backward(P, S, dseg, E):
     G['low_level_fuse.conv.weight'] = ops.gemm_tn(dzl, S['cat2'])
     dcat2 = ops.gemm_nt(dzl, w_bwd(P['low_level_fuse.conv.weight'], T))
     dc1 = dcat2[:, E:]
-    G['linear_c1.proj.weight'] = ops.gemm_tn(dc1, t[0])
-    G['linear_c1.proj.bias'] = ops.colsum(dc1)[0]
+    G['linear_c1.proj.weight'], G['linear_c1.proj.bias'] = ops.gemm_tn(dc1, t[0], colsum=True)
     dt = [ops.gemm_nt(dc1, w_bwd(P['linear_c1.proj.weight'], T)), None, None, None]
     # cat
     dz4, dgb = ops.bn_bwd(dcat2[:, :E], S['z4'], S['stc'], P['cat.bn.weight'], P['cat.bn.bias'], act=1, training=training)
@@ -154,11 +153,9 @@ def head_backward(P, S, dseg, E):
         G[f'{p}.conv_out.0.weight'] = ops.gemm_tn(dz, br['y'])
         dy = ops.gemm_nt(dz, w_bwd(P[f'{p}.conv_out.0.weight'], T))
         dth, dpg = ops.lawin_attn_bwd(br['th'], br['pg'], br['y'], dy, br['lse'], B, H8, W8, heads)
-        G[f'{p}.theta.weight'] = ops.gemm_tn(dth, feat)
-        G[f'{p}.theta.bias'] = ops.colsum(dth)[0]
+        G[f'{p}.theta.weight'], G[f'{p}.theta.bias'] = ops.gemm_tn(dth, feat, colsum=True)
         acc = ops.gemm_nt(dth, w_bwd(P[f'{p}.theta.weight'], T), res=acc)
-        dwpg = ops.gemm_tn(dpg, br['ctx'])
-        dbpg = ops.colsum(dpg)[0]
+        dwpg, dbpg = ops.gemm_tn(dpg, br['ctx'], colsum=True)
         G[f'{p}.phi.weight'], G[f'{p}.g.weight'] = dwpg[:inter], dwpg[inter:]
         G[f'{p}.phi.bias'], G[f'{p}.g.bias'] = dbpg[:inter], dbpg[inter:]
         dctxp = ops.gemm_nt(dpg, ops.transpose_cast(br['wpg'].contiguous(), T))
@@ -180,8 +177,7 @@ def head_backward(P, S, dseg, E):
         if lvl > 1:
             d = ops.bilinear_bwd(d, B, hw[lvl][0], hw[lvl][1], H8, W8)
         name = f'linear_c{lvl + 1}.proj'
-        G[name + '.weight'] = ops.gemm_tn(d, t[lvl])
-        G[name + '.bias'] = ops.colsum(d)[0]
+        G[name + '.weight'], G[name + '.bias'] = ops.gemm_tn(d, t[lvl], colsum=True)
         dt[lvl] = ops.gemm_nt(d, w_bwd(P[name + '.weight'], T))
     return dt, G
 

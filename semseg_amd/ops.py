@@ -86,8 +86,8 @@ def gemm_nt(a, b, out=None, bias=None, res=None, rowscale=None, rows_per_scale=0
     return out
 
 
-def gemm_tn(a, b, out=None, accumulate=False):
-    """out[M,N] (fp32) (+)= a[R,M]^T @ b[R,N]."""
+def gemm_tn(a, b, out=None, accumulate=False, colsum=False):
+    """out[M,N] (fp32) (+)= a[R,M]^T @ b[R,N].  colsum=True -> (out, column sums of a [M] fp32) from the same pass."""
     dev = _dev(a)
     R, M, lda = _mat(a, 'a')
     Rb, N, ldb = _mat(b, 'b')
@@ -102,8 +102,16 @@ def gemm_tn(a, b, out=None, accumulate=False):
         raise ValueError('gemm_tn: bad out')
     nbytes = lib().ss_gemm_tn_workspace(dt(a), M, N, R)
     ws = workspace(dev, nbytes)
-    check(lib().ss_gemm_tn(dt(a), _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, R, _p(ws), ws.numel(), int(accumulate), _stream()))
-    return out
+    if not colsum:
+        check(lib().ss_gemm_tn(dt(a), _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, R, _p(ws), ws.numel(), int(accumulate), _stream()))
+        return out
+    if M % 8 or lda % 8:
+        check(lib().ss_gemm_tn(dt(a), _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, R, _p(ws), ws.numel(), int(accumulate), _stream()))
+        return out, colsum_any(a)
+    cs = torch.empty(M, dtype=torch.float32, device=dev)
+    check(lib().ss_gemm_tn_colsum(dt(a), _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, R, _p(ws), ws.numel(), int(accumulate), _p(cs), 0,
+                                  _stream()))
+    return out, cs
 
 
 # ------------------------------------------------------------------ norms / reductions

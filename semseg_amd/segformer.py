@@ -28,9 +28,9 @@ def w_bwd(w, dtype):
 
 def linear_grads(dout, x_in, want_bias=True):
     """-> (dW [N, K] fp32, db [N] fp32)."""
-    dw = ops.gemm_tn(dout, x_in)
-    db = ops.colsum(dout)[0] if want_bias else None
-    return dw, db
+    if want_bias:
+        return ops.gemm_tn(dout, x_in, colsum=True)
+    return ops.gemm_tn(dout, x_in), None
 
 
 # ------------------------------------------------------------------ attention (modules/segformer.py:21-41)
@@ -71,9 +71,8 @@ def attn_backward(P, S, dout, B, h, w, head, sr):
     if sr > 1:
         ds, dgb = ops.layernorm_bwd(dxr, S['s'], S['m'], S['r'], P['norm.weight'])
         G['norm.weight'], G['norm.bias'] = dgb[0], dgb[1]
-        gp = ops.gemm_tn(ds, S['col'])
+        gp, G['sr.bias'] = ops.gemm_tn(ds, S['col'], colsum=True)
         G['sr.weight'] = ops.unpack_conv_wgrad(gp, C, C, sr)
-        G['sr.bias'] = ops.colsum(ds)[0]
         _, wpt = ops.pack_conv_weight(P['sr.weight'].detach(), T, transposed=True)
         dxa = ops.col2im(ops.gemm_nt(ds, wpt), B, h, w, C, sr, sr, 0)
     else:
@@ -233,8 +232,9 @@ class PatchEmbedFn(_ParamFn):
         T = dy.dtype
         Cout = dy.shape[1]
         dz, dgb = ops.layernorm_bwd(dy, S['z'], S['m'], S['r'], P['norm.weight'])
-        G = {'norm.weight': dgb[0], 'norm.bias': dgb[1], 'proj.bias': ops.colsum(dz)[0]}
-        G['proj.weight'] = ops.unpack_conv_wgrad(ops.gemm_tn(dz, S['col']), Cout, Cin, k)
+        G = {'norm.weight': dgb[0], 'norm.bias': dgb[1]}
+        gp, G['proj.bias'] = ops.gemm_tn(dz, S['col'], colsum=True)
+        G['proj.weight'] = ops.unpack_conv_wgrad(gp, Cout, Cin, k)
         dx = None
         if Cin % 8 == 0:                                      # the RGB image (stage 1) needs no gradient
             _, wpt = ops.pack_conv_weight(P['proj.weight'].detach(), T, transposed=True)

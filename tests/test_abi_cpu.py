@@ -10,7 +10,7 @@ from semseg_amd import _lib
 
 def test_header_parses_and_lists_entry_points():
     protos = _lib.parse_header()
-    for name in ('ss_gemm_nt', 'ss_gemm_tn', 'ss_layernorm_fwd', 'ss_mit_attn_fwd', 'ss_mit_attn_bwd', 'ss_dwconv3_fwd',
+    for name in ('ss_gemm_nt', 'ss_gemm_tn', 'ss_gemm_tn_colsum', 'ss_layernorm_fwd', 'ss_mit_attn_fwd', 'ss_mit_attn_bwd', 'ss_dwconv3_fwd',
                  'ss_bn_stats', 'ss_bilinear_fwd', 'ss_last_error', 'ss_version'):
         assert name in protos
     assert protos['ss_version'][1] == []

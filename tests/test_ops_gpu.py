@@ -90,6 +90,20 @@ def test_gemm_tn_bf16_fast_path(ops, R, M, N):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('R,M,N', [(5000, 64, 64), (70001, 320, 136), (9000, 512, 48 + 512), (300, 8, 16), (4097, 6, 512), (100000, 1280, 320)])
+def test_gemm_tn_with_bias_gradient(ops, dtype, R, M, N):
+    """ss_gemm_tn_colsum: dW = dY^T X and db = column sums of dY from one pass (fused in the bf16 MFMA kernel, a second launch on
+    the other paths); must agree with the two separate entry points."""
+    a, b = rnd(R, M), rnd(R, N, seed=1)
+    out, cs = ops.gemm_tn(dev(a, dtype), dev(b, dtype), colsum=True)
+    ref = q(a, dtype).t() @ q(b, dtype)
+    assert rel(out, ref) < (1e-2 if dtype == torch.bfloat16 else 1e-4)
+    assert float((out - ops.gemm_tn(dev(a, dtype), dev(b, dtype))).abs().max()) == 0
+    refcs = q(a, dtype).double().sum(0).float()
+    assert float((cs.cpu() - refcs).abs().max()) <= 1e-4 * float(q(a, dtype).abs().double().sum(0).max())
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_gemm_nt_strided(ops, dtype):
     big_a, b = rnd(200, 96), rnd(40, 32, seed=1)
     a = dev(big_a, dtype)[:, 32:64]
