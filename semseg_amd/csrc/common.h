@@ -93,7 +93,7 @@ __device__ __forceinline__ float group_max(float v, int lanes) {
 // derivative, instead of libm erff + expf (the GELU kernels are otherwise VALU-bound on an HBM-bound op).
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ez) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);     // v_rcp_f32 (1 ulp), not the IEEE division sequence
     ez = __expf(-z * z);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float hc = 0.5f * poly * ez;                       // 0.5 erfc(|z|)

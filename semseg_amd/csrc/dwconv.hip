@@ -11,7 +11,8 @@
 #include "common.h"
 #include "colreduce.h"
 
-#define DW_TY 16
+#define DW_TY 18                                      // rows per strip
+#define DW_UNROLL 9                                   // rows per loop iteration: divides DW_TY, a multiple of the window height 3
 
 template <typename T, int N> using vecn = T __attribute__((ext_vector_type(N)));
 
@@ -35,31 +36,99 @@ static inline DwGeom dw_geom(int H, int W, int C, int ne) {
     return g;
 }
 
-// one row of the window: columns x-1, x, x+1 of image row yy (zeros outside the image)
+// One row of the window in storage dtype: columns x-1, x, x+1 of a row that EXISTS (the caller clamps the row, offL / offR are
+// -C / +C or 0 at the image border).  Always three unconditional loads: a load under a branch cannot stay in flight across
+// the steps of the row loop, the compiler waits for it at the join.  What a clamped load fetched is discarded where it is used:
+// border columns through zeroed taps (forward) or masked gradients (backward), the row below the image through `keep`.
 template <typename T, int NE>
-__device__ __forceinline__ void dw_load_row(const T* __restrict__ x, int64_t img_base, int yy, int xx, int H, int W, int C, int c,
-                                            vecn<T, NE> (&row)[3]) {
-    const bool yok = yy >= 0 && yy < H;
+__device__ __forceinline__ void dw_issue_row(const T* __restrict__ p, int offL, int offR, vecn<T, NE> (&row)[3]) {
+    row[1] = raw_load<T, NE>(p);
+    row[0] = raw_load<T, NE>(p + offL);
+    row[2] = raw_load<T, NE>(p + offR);
+}
+// the window itself is kept in fp32: every input is converted once, when it enters, not once per tap it takes part in.
+// keep[kx] = ~0u, or 0 where column kx of this row lies outside the image (AND on the raw bits: bf16 / fp32 +0)
+template <typename T, int NE>
+__device__ __forceinline__ void dw_cvt_row(const vecn<T, NE> (&raw)[3], unsigned keepL, unsigned keepC, unsigned keepR, float (&row)[3][NE]) {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-        const int sx = xx + kx - 1;
-        vecn<T, NE> v;
+        const unsigned keep = kx == 0 ? keepL : kx == 1 ? keepC : keepR;
+        union { vecn<T, NE> v; unsigned u[sizeof(vecn<T, NE>) / 4]; } m;
+        m.v = raw[kx];
 #pragma unroll
-        for (int e = 0; e < NE; ++e) v[e] = (T)0.f;
-        if (yok && sx >= 0 && sx < W) v = raw_load<T, NE>(x + (img_base + (int64_t)yy * W + sx) * C + c);
-        row[kx] = v;
+        for (int i = 0; i < (int)(sizeof(vecn<T, NE>) / 4); ++i) m.u[i] &= keep;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) row[kx][e] = (float)m.v[e];
     }
 }
 
-template <typename T, int NE>
-__global__ __launch_bounds__(256) void dwconv3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-        T* __restrict__ y, int H, int W, int C, int act, DwGeom g) {
+// The scheduler may move memory and scalar instructions across these points, vector arithmetic stays in source order: hipcc
+// otherwise emits each accumulator's whole dependent chain back to back (a stall per instruction at two waves per SIMD).
+#define DW_PIN_VALU() __builtin_amdgcn_sched_barrier(0x0004 | 0x0010 | 0x0080)
+
+// tap-major: the NE accumulators advance together, so consecutive instructions are independent
+template <int NE>
+__device__ __forceinline__ void dw_taps(const float (&top)[3][NE], const float (&mid)[3][NE], const float (&bot)[3][NE],
+                                        const float (&wt)[9][NE], const float (&bv)[NE], float (&u)[NE]) {
+    float a[NE], b[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { u[e] = fmaf(top[0][e], wt[0][e], bv[e]); a[e] = mid[0][e] * wt[3][e]; b[e] = bot[0][e] * wt[6][e]; }
+    DW_PIN_VALU();
+#pragma unroll
+    for (int kx = 1; kx < 3; ++kx) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            u[e] = fmaf(top[kx][e], wt[kx][e], u[e]);
+            a[e] = fmaf(mid[kx][e], wt[3 + kx][e], a[e]);
+            b[e] = fmaf(bot[kx][e], wt[6 + kx][e], b[e]);
+        }
+        DW_PIN_VALU();
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) u[e] += a[e] + b[e];
+    DW_PIN_VALU();
+}
+
+// GELU pieces for NE values at once, stage by stage (same formula as gelu_parts in common.h)
+template <int NE>
+__device__ __forceinline__ void gelu_parts_v(const float (&x)[NE], float (&cdf)[NE], float (&ez)[NE]) {
+    float z[NE], t[NE], p[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { z[e] = fabsf(x[e]) * 0.70710678118654752f; t[e] = fmaf(0.3275911f, z[e], 1.f); }
+    DW_PIN_VALU();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { t[e] = __builtin_amdgcn_rcpf(t[e]); z[e] = -z[e] * z[e]; }
+    DW_PIN_VALU();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { ez[e] = __expf(z[e]); p[e] = fmaf(t[e], 1.061405429f, -1.453152027f); }
+    DW_PIN_VALU();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) p[e] = fmaf(t[e], p[e], 1.421413741f);
+    DW_PIN_VALU();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) p[e] = fmaf(t[e], p[e], -0.284496736f);
+    DW_PIN_VALU();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) p[e] = fmaf(t[e], p[e], 0.254829592f);
+    DW_PIN_VALU();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) p[e] = 0.5f * (t[e] * p[e]);
+    DW_PIN_VALU();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { const float hc = p[e] * ez[e]; cdf[e] = x[e] >= 0.f ? 1.f - hc : hc; }
+    DW_PIN_VALU();
+}
+
+// Row r of the strip reaches the window through a ring of 3 raw rows: its loads are issued three steps before the step that
+// converts it, so a wave's own arithmetic covers its own HBM latency (two waves per SIMD suffice).
+template <typename T, int NE, int ACT>
+__global__ __launch_bounds__(256, 2) void dwconv3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+        T* __restrict__ y, int H, int W, int C, DwGeom g) {
     typedef vecn<T, NE> V;
     const int tid = threadIdx.x, chunk = blockIdx.y * g.cpb + tid % g.cpb, xs = tid / g.cpb;
     const int xt = blockIdx.x % g.xtiles, ys = blockIdx.x / g.xtiles;
     const int xx = xt * g.xl + xs, y0 = ys * DW_TY, c = chunk * NE;
     if (chunk >= g.chunks || xx >= W) return;
-    const int64_t img_base = (int64_t)blockIdx.z * H * W;
     float wt[9][NE], bv[NE];
 #pragma unroll
     for (int k = 0; k < 9; ++k) loadf<NE>(w + k * C + c, wt[k]);
@@ -67,36 +136,58 @@ __global__ __launch_bounds__(256) void dwconv3_fwd_kernel(const T* __restrict__ 
     else {
 #pragma unroll
         for (int e = 0; e < NE; ++e) bv[e] = 0.f; }
-    V win[3][3];
-    dw_load_row<T, NE>(x, img_base, y0 - 1, xx, H, W, C, c, win[0]);
-    dw_load_row<T, NE>(x, img_base, y0, xx, H, W, C, c, win[1]);
-    dw_load_row<T, NE>(x, img_base, y0 + 1, xx, H, W, C, c, win[2]);
+    const bool lok = xx > 0, rok = xx + 1 < W;
+    const unsigned mL = lok ? ~0u : 0u, mR = rok ? ~0u : 0u;
+    const int offL = lok ? -C : 0, offR = rok ? C : 0;
+    const int64_t rs = (int64_t)W * C;
+    const int64_t off = (((int64_t)blockIdx.z * H + y0) * W + xx) * C + c;
+    const T* px = x + off;                                 // row y0 of this thread's column
+    T* py = y + off;
     const int yend = min(H, y0 + DW_TY);
-    for (int yy = y0; yy < yend; ++yy) {
-        V nxt[3];                                          // row yy+2 travels while row yy is computed
-        dw_load_row<T, NE>(x, img_base, yy + 2 <= yend ? yy + 2 : H, xx, H, W, C, c, nxt);
-        float u[NE];
+    const int ylast = min(H - 1, yend);                    // last row any output of the strip reads
+    float win[3][3][NE];
+    V ring[3][3];
+    {
+        V raw[3];
+        unsigned k = y0 > 0 ? ~0u : 0u;
+        dw_issue_row<T, NE>(px - (y0 > 0 ? rs : 0), offL, offR, raw); dw_cvt_row<T, NE>(raw, mL & k, k, mR & k, win[0]);
+        dw_issue_row<T, NE>(px, offL, offR, raw); dw_cvt_row<T, NE>(raw, mL, ~0u, mR, win[1]);
+        k = y0 + 1 < H ? ~0u : 0u;
+        dw_issue_row<T, NE>(px + (y0 + 1 < H ? rs : 0), offL, offR, raw); dw_cvt_row<T, NE>(raw, mL & k, k, mR & k, win[2]);
 #pragma unroll
-        for (int e = 0; e < NE; ++e) u[e] = bv[e];
+        for (int j = 0; j < 3; ++j) dw_issue_row<T, NE>(px + (min(y0 + 2 + j, ylast) - y0) * rs, offL, offR, ring[(2 + j) % 3]);
+    }
+    // Branch-free steps (a row past the strip's end is computed from clamped loads and not stored), DW_UNROLL rows per loop
+    // iteration: the compiler's wait counts are exact inside an iteration and conservative only across the back edge.
+    for (int yy = y0; yy < yend; yy += DW_UNROLL) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int i = 0; i < DW_UNROLL; ++i) {               // window rows rotate through the three slots: no register moves
+            const int yc = yy + i;
+            float u[NE];
+            dw_taps<NE>(win[i % 3], win[(i + 1) % 3], win[(i + 2) % 3], wt, bv, u);
+            V o;
+            if (ACT == 1) {
+                float cdf[NE], ez[NE];
+                gelu_parts_v<NE>(u, cdf, ez);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+                for (int e = 0; e < NE; ++e) o[e] = (T)(u[e] * cdf[e]);
+            } else {
 #pragma unroll
-                for (int e = 0; e < NE; ++e) u[e] += (float)win[ky][kx][e] * wt[ky * 3 + kx][e];
-        V o;
-#pragma unroll
-        for (int e = 0; e < NE; ++e) o[e] = (T)(act == 1 ? gelu_erf(u[e]) : u[e]);
-        *(V*)(y + (img_base + (int64_t)yy * W + xx) * C + c) = o;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) { win[0][kx] = win[1][kx]; win[1][kx] = win[2][kx]; win[2][kx] = nxt[kx]; }
+                for (int e = 0; e < NE; ++e) o[e] = (T)u[e];
+            }
+            if (yc < yend) *(V*)(py + i * rs) = o;
+            const unsigned k = yc + 2 < H ? ~0u : 0u;
+            dw_cvt_row<T, NE>(ring[(i + 2) % 3], mL & k, k, mR & k, win[i % 3]);                   // row yc+2 enters the window
+            dw_issue_row<T, NE>(px + (min(yc + 5, ylast) - yy) * rs, offL, offR, ring[(i + 2) % 3]);  // row yc+5 starts travelling
+        }
+        px += DW_UNROLL * rs; py += DW_UNROLL * rs;
     }
 }
 
 // g = dy * act'(u);  partial[blockIdx.x][10][C]: taps 0..8 = sum g * x(tap), 9 = sum g   (this workgroup's channel group only)
-template <typename T, int NE>
+template <typename T, int NE, int ACT>
 __global__ __launch_bounds__(256) void dwconv3_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ w,
-        const float* __restrict__ bias, T* __restrict__ gout, float* __restrict__ partial, int B, int H, int W, int C, int act, DwGeom g) {
+        const float* __restrict__ bias, T* __restrict__ gout, float* __restrict__ partial, int B, int H, int W, int C, DwGeom g) {
     typedef vecn<T, NE> V;
     __shared__ float sh[256 * NE];
     const int tid = threadIdx.x, cl = tid % g.cpb, chunk = blockIdx.y * g.cpb + cl, xs = tid / g.cpb, c = chunk * NE;
@@ -111,49 +202,76 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_kernel(const T* __restrict__ 
         for (int k = 0; k < 9; ++k) loadf<NE>(w + k * C + c, wt[k]);
         loadf<NE>(bias + c, bv);
         const int tiles_per_img = g.xtiles * g.ystrips, ntiles = B * tiles_per_img;
+        const int64_t rs = (int64_t)W * C;
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             const int img = tile / tiles_per_img, rem = tile % tiles_per_img;
             const int xx = (rem % g.xtiles) * g.xl + xs, y0 = (rem / g.xtiles) * DW_TY;
             if (xx >= W) continue;
-            const int64_t img_base = (int64_t)img * H * W;
-            V win[3][3];
-            dw_load_row<T, NE>(x, img_base, y0 - 1, xx, H, W, C, c, win[0]);
-            dw_load_row<T, NE>(x, img_base, y0, xx, H, W, C, c, win[1]);
-            dw_load_row<T, NE>(x, img_base, y0 + 1, xx, H, W, C, c, win[2]);
+            const bool lok = xx > 0, rok = xx + 1 < W;
+            const unsigned mL = lok ? ~0u : 0u, mR = rok ? ~0u : 0u;
+            const int offL = lok ? -C : 0, offR = rok ? C : 0;
+            const int64_t off = (((int64_t)img * H + y0) * W + xx) * C + c;
+            const T* px = x + off;
+            const T* pd = dy + off;
+            T* pg = gout + off;
             const int yend = min(H, y0 + DW_TY);
-            V d = raw_load<T, NE>(dy + (img_base + (int64_t)y0 * W + xx) * C + c);
-            for (int yy = y0; yy < yend; ++yy) {
-                V nxt[3], dn = d;                              // row yy+2 of x and row yy+1 of dy travel while row yy is computed
-                dw_load_row<T, NE>(x, img_base, yy + 2 <= yend ? yy + 2 : H, xx, H, W, C, c, nxt);
-                const int64_t p = img_base + (int64_t)yy * W + xx;
-                if (yy + 1 < yend) dn = raw_load<T, NE>(dy + (p + W) * C + c);
-                float u[NE], go[NE];
+            const int ylast = min(H - 1, yend);
+            float win[3][3][NE];
+            V ring[3][3], dring[3];
+            {
+                V raw[3];
+                unsigned k = y0 > 0 ? ~0u : 0u;
+                dw_issue_row<T, NE>(px - (y0 > 0 ? rs : 0), offL, offR, raw); dw_cvt_row<T, NE>(raw, mL & k, k, mR & k, win[0]);
+                dw_issue_row<T, NE>(px, offL, offR, raw); dw_cvt_row<T, NE>(raw, mL, ~0u, mR, win[1]);
+                k = y0 + 1 < H ? ~0u : 0u;
+                dw_issue_row<T, NE>(px + (y0 + 1 < H ? rs : 0), offL, offR, raw); dw_cvt_row<T, NE>(raw, mL & k, k, mR & k, win[2]);
 #pragma unroll
-                for (int e = 0; e < NE; ++e) u[e] = bv[e];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                        for (int e = 0; e < NE; ++e) u[e] += (float)win[ky][kx][e] * wt[ky * 3 + kx][e];
-                V gv;
-#pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    go[e] = act == 1 ? (float)d[e] * gelu_erf_grad(u[e]) : (float)d[e];
-                    gv[e] = (T)go[e];
-                    go[e] = (float)gv[e];                 // dW uses the stored (rounded) g, as a separate pass over g would
-                    acc[9][e] += go[e];
+                for (int j = 0; j < 3; ++j) {
+                    dw_issue_row<T, NE>(px + (min(y0 + 2 + j, ylast) - y0) * rs, offL, offR, ring[(2 + j) % 3]);
+                    dring[j] = raw_load<T, NE>(pd + (min(y0 + j, yend - 1) - y0) * rs);
                 }
-                *(V*)(gout + p * C + c) = gv;
+            }
+            for (int yy = y0; yy < yend; yy += DW_UNROLL) {
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int i = 0; i < DW_UNROLL; ++i) {
+                    const int yc = yy + i;
+                    float u[NE], go[NE];
+                    dw_taps<NE>(win[i % 3], win[(i + 1) % 3], win[(i + 2) % 3], wt, bv, u);
+                    union { V v; unsigned w[sizeof(V) / 4]; } d;
+                    d.v = dring[i % 3];
+                    const unsigned live = yc < yend ? ~0u : 0u;          // a row past the strip's end contributes nothing
+#pragma unroll
+                    for (int j = 0; j < (int)(sizeof(V) / 4); ++j) d.w[j] &= live;
+                    dring[i % 3] = raw_load<T, NE>(pd + (min(yc + 3, yend - 1) - yy) * rs);   // row yc+3 of dy starts travelling
+                    V gv;
+                    float dact[NE];
+                    if (ACT == 1) {
+                        float cdf[NE], ez[NE];
+                        gelu_parts_v<NE>(u, cdf, ez);
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) dact[e] = fmaf(u[e] * 0.3989422804014327f, ez[e], cdf[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        go[e] = ACT == 1 ? (float)d.v[e] * dact[e] : (float)d.v[e];
+                        gv[e] = (T)go[e];
+                        go[e] = (float)gv[e];             // dW uses the stored (rounded) g, as a separate pass over g would
+                        acc[9][e] += go[e];
+                    }
+                    if (yc < yend) *(V*)(pg + i * rs) = gv;
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                        for (int e = 0; e < NE; ++e) acc[ky * 3 + kx][e] += go[e] * (float)win[ky][kx][e];
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) { win[0][kx] = win[1][kx]; win[1][kx] = win[2][kx]; win[2][kx] = nxt[kx]; }
-                d = dn;
+                        for (int e = 0; e < NE; ++e) {
+                            acc[kx][e] = fmaf(go[e], win[i % 3][kx][e], acc[kx][e]);
+                            acc[3 + kx][e] = fmaf(go[e], win[(i + 1) % 3][kx][e], acc[3 + kx][e]);
+                            acc[6 + kx][e] = fmaf(go[e], win[(i + 2) % 3][kx][e], acc[6 + kx][e]);
+                        }
+                    const unsigned k = yc + 2 < H ? ~0u : 0u;
+                    dw_cvt_row<T, NE>(ring[(i + 2) % 3], mL & k, k, mR & k, win[i % 3]);
+                    dw_issue_row<T, NE>(px + (min(yc + 5, ylast) - yy) * rs, offL, offR, ring[(i + 2) % 3]);
+                }
+                px += DW_UNROLL * rs; pd += DW_UNROLL * rs; pg += DW_UNROLL * rs;
             }
         }
     }
@@ -181,9 +299,12 @@ extern "C" int ss_dwconv3_fwd(int dtype, const void* x, const float* w9c, const 
     DwGeom g = dw_geom(H, W, C, dtype == SS_BF16 ? 8 : 4);
     SS_CHECK((int64_t)g.xtiles * g.ystrips < 2147483647LL && B < 65536 && g.groups < 65536, "ss_dwconv3_fwd: grid too large");
     dim3 grid((unsigned)(g.xtiles * g.ystrips), g.groups, B);
-    if (dtype == SS_BF16) hipLaunchKernelGGL((dwconv3_fwd_kernel<bf16, 8>), grid, dim3(256), 0, stream, (const bf16*)x, w9c, bias, (bf16*)y, H, W, C, act, g);
-    else if (dtype == SS_F32) hipLaunchKernelGGL((dwconv3_fwd_kernel<float, 4>), grid, dim3(256), 0, stream, (const float*)x, w9c, bias, (float*)y, H, W, C, act, g);
+    SS_CHECK(act == 0 || act == 1, "ss_dwconv3_fwd: act must be 0 (none) or 1 (GELU)");
+#define SS_DW_FWD(T, NE, ACT) hipLaunchKernelGGL((dwconv3_fwd_kernel<T, NE, ACT>), grid, dim3(256), 0, stream, (const T*)x, w9c, bias, (T*)y, H, W, C, g)
+    if (dtype == SS_BF16) { if (act) SS_DW_FWD(bf16, 8, 1); else SS_DW_FWD(bf16, 8, 0); }
+    else if (dtype == SS_F32) { if (act) SS_DW_FWD(float, 4, 1); else SS_DW_FWD(float, 4, 0); }
     else return ss_fail(-1, "ss_dwconv3_fwd: unsupported dtype %d", dtype);
+#undef SS_DW_FWD
     SS_LAUNCH_CHECK();
     return 0;
 }
@@ -199,9 +320,12 @@ extern "C" int ss_dwconv3_bwd(int dtype, const void* dy, const void* x, const fl
     int64_t nbg = 1024 / geo.groups; if (nbg < 1) nbg = 1; if (nbg > ntiles) nbg = ntiles;
     SS_CHECK(ws_bytes >= nbg * 10 * C * 4, "ss_dwconv3_bwd: workspace too small");
     dim3 grid((unsigned)nbg, geo.groups);
-    if (dtype == SS_BF16) hipLaunchKernelGGL((dwconv3_bwd_kernel<bf16, 4>), grid, dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, w9c, bias, (bf16*)g, workspace, B, H, W, C, act, geo);
-    else if (dtype == SS_F32) hipLaunchKernelGGL((dwconv3_bwd_kernel<float, 4>), grid, dim3(256), 0, stream, (const float*)dy, (const float*)x, w9c, bias, (float*)g, workspace, B, H, W, C, act, geo);
+    SS_CHECK(act == 0 || act == 1, "ss_dwconv3_bwd: act must be 0 (none) or 1 (GELU)");
+#define SS_DW_BWD(T, NE, ACT) hipLaunchKernelGGL((dwconv3_bwd_kernel<T, NE, ACT>), grid, dim3(256), 0, stream, (const T*)dy, (const T*)x, w9c, bias, (T*)g, workspace, B, H, W, C, geo)
+    if (dtype == SS_BF16) { if (act) SS_DW_BWD(bf16, 4, 1); else SS_DW_BWD(bf16, 4, 0); }
+    else if (dtype == SS_F32) { if (act) SS_DW_BWD(float, 4, 1); else SS_DW_BWD(float, 4, 0); }
     else return ss_fail(-1, "ss_dwconv3_bwd: unsupported dtype %d", dtype);
+#undef SS_DW_BWD
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(10 * C, 8), 1), dim3(256), 0, stream, workspace, (int)nbg, 10 * C, 1.f, dw_db, 0);
     SS_LAUNCH_CHECK();
