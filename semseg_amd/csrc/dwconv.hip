@@ -11,8 +11,7 @@
 #include "common.h"
 #include "colreduce.h"
 
-#define DW_TY 18                                      // rows per strip
-#define DW_UNROLL 9                                   // rows per loop iteration: divides DW_TY, a multiple of the window height 3
+#define DW_UNROLL 9                                   // rows per loop iteration: divides the strip height, a multiple of the window height 3
 
 template <typename T, int N> using vecn = T __attribute__((ext_vector_type(N)));
 
@@ -26,13 +25,23 @@ template <int NE> __device__ __forceinline__ void loadf(const float* p, float (&
         for (int e = 0; e < 4; ++e) o[4 * i + e] = a[e]; }
 }
 
-struct DwGeom { int cpb, xl, groups, xtiles, ystrips, chunks; };
-static inline DwGeom dw_geom(int H, int W, int C, int ne) {
+struct DwGeom { int cpb, xl, groups, xtiles, ystrips, chunks, ty; };
+static inline DwGeom dw_geom(int B, int H, int W, int C, int ne) {
     DwGeom g; g.chunks = C / ne;
     const int cap = ne == 8 ? 32 : 64;
     int cpb = 1; while (cpb < g.chunks && cpb < cap) cpb <<= 1;
     g.cpb = cpb; g.xl = 256 / cpb; g.groups = (int)cdiv(g.chunks, cpb);
-    g.xtiles = (int)cdiv(W, g.xl); g.ystrips = (int)cdiv(H, DW_TY);
+    g.xtiles = (int)cdiv(W, g.xl);
+    // rows per strip: a multiple of DW_UNROLL.  Taller strips amortise the fill of window + ring and the 2 halo rows (about 6 rows
+    // of work per strip); rows past the image bottom are computed and dropped; and the launch wants >= 8 workgroups per CU.
+    int best = 2 * DW_UNROLL; int64_t best_cost = -1;
+    for (int ty = 2 * DW_UNROLL; ty <= 8 * DW_UNROLL; ty += DW_UNROLL) {
+        const int64_t strips = cdiv(H, ty), cost = strips * (ty + 6);
+        const int64_t blocks = strips * g.xtiles * g.groups * B;
+        if (ty > 2 * DW_UNROLL && blocks < 2048) break;
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = ty; }
+    }
+    g.ty = best; g.ystrips = (int)cdiv(H, g.ty);
     return g;
 }
 
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3_fwd_kernel(const T* __restrict
     typedef vecn<T, NE> V;
     const int tid = threadIdx.x, chunk = blockIdx.y * g.cpb + tid % g.cpb, xs = tid / g.cpb;
     const int xt = blockIdx.x % g.xtiles, ys = blockIdx.x / g.xtiles;
-    const int xx = xt * g.xl + xs, y0 = ys * DW_TY, c = chunk * NE;
+    const int xx = xt * g.xl + xs, y0 = ys * g.ty, c = chunk * NE;
     if (chunk >= g.chunks || xx >= W) return;
     float wt[9][NE], bv[NE];
 #pragma unroll
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3_fwd_kernel(const T* __restrict
     const int64_t off = (((int64_t)blockIdx.z * H + y0) * W + xx) * C + c;
     const T* px = x + off;                                 // row y0 of this thread's column
     T* py = y + off;
-    const int yend = min(H, y0 + DW_TY);
+    const int yend = min(H, y0 + g.ty);
     const int ylast = min(H - 1, yend);                    // last row any output of the strip reads
     float win[3][3][NE];
     V ring[3][3];
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_kernel(const T* __restrict__ 
         const int64_t rs = (int64_t)W * C;
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             const int img = tile / tiles_per_img, rem = tile % tiles_per_img;
-            const int xx = (rem % g.xtiles) * g.xl + xs, y0 = (rem / g.xtiles) * DW_TY;
+            const int xx = (rem % g.xtiles) * g.xl + xs, y0 = (rem / g.xtiles) * g.ty;
             if (xx >= W) continue;
             const bool lok = xx > 0, rok = xx + 1 < W;
             const unsigned mL = lok ? ~0u : 0u, mR = rok ? ~0u : 0u;
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_kernel(const T* __restrict__ 
             const T* px = x + off;
             const T* pd = dy + off;
             T* pg = gout + off;
-            const int yend = min(H, y0 + DW_TY);
+            const int yend = min(H, y0 + g.ty);
             const int ylast = min(H - 1, yend);
             float win[3][3][NE];
             V ring[3][3], dring[3];
@@ -296,7 +305,7 @@ extern "C" int ss_dwconv3_fwd(int dtype, const void* x, const float* w9c, const 
                               int act, hipStream_t stream) {
     SS_CHECK(x && w9c && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "ss_dwconv3_fwd: bad arguments (C=%d)", C);
     SS_CHECK(aligned16(x) && aligned16(y) && aligned16(w9c) && (!bias || aligned16(bias)), "ss_dwconv3_fwd: pointers must be 16-byte aligned");
-    DwGeom g = dw_geom(H, W, C, dtype == SS_BF16 ? 8 : 4);
+    DwGeom g = dw_geom(B, H, W, C, dtype == SS_BF16 ? 8 : 4);
     SS_CHECK((int64_t)g.xtiles * g.ystrips < 2147483647LL && B < 65536 && g.groups < 65536, "ss_dwconv3_fwd: grid too large");
     dim3 grid((unsigned)(g.xtiles * g.ystrips), g.groups, B);
     SS_CHECK(act == 0 || act == 1, "ss_dwconv3_fwd: act must be 0 (none) or 1 (GELU)");
@@ -314,7 +323,7 @@ extern "C" int ss_dwconv3_bwd(int dtype, const void* dy, const void* x, const fl
                               int B, int H, int W, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream) {
     SS_CHECK(dy && x && w9c && bias && g && dw_db && workspace && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "ss_dwconv3_bwd: bad arguments");
     SS_CHECK(aligned16(x) && aligned16(dy) && aligned16(g) && aligned16(w9c) && aligned16(bias), "ss_dwconv3_bwd: pointers must be 16-byte aligned");
-    DwGeom geo = dw_geom(H, W, C, 4);
+    DwGeom geo = dw_geom(B, H, W, C, 4);
     const int64_t ntiles = (int64_t)B * geo.xtiles * geo.ystrips;
     SS_CHECK(ntiles < 2147483647LL && geo.groups < 65536, "ss_dwconv3_bwd: grid too large");
     int64_t nbg = 1024 / geo.groups; if (nbg < 1) nbg = 1; if (nbg > ntiles) nbg = ntiles;
