@@ -117,16 +117,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // Mish(x) = x * tanh(softplus(x)).  With e = exp(x) and n = e (e + 2):  tanh(log(1 + e)) = n / (n + 2)  (no cancellation),
 // 1 - tanh^2 = 4 (n + 1) / (n + 2)^2, sigmoid = e / (1 + e): one expf and two divisions instead of expf + log1pf + tanhf.
 // x > 20: Mish(x) = x to fp32 precision (torch's softplus threshold); x << 0: e underflows to 0 and both forms return 0.
+// Branch-free: e is taken at min(x, 20) (beyond it both forms are 1 to fp32 precision); v_exp_f32 and v_rcp_f32 (~1 ulp each).
 __device__ __forceinline__ float mish_f(float x) {
-    if (x > 20.f) return x;
-    float e = expf(x), n = e * (e + 2.f);
-    return x * (n / (n + 2.f));
+    const float e = __expf(fminf(x, 20.f)), n = e * (e + 2.f);
+    return x * (n * __builtin_amdgcn_rcpf(n + 2.f));
 }
 __device__ __forceinline__ float mish_grad(float x) {
-    if (x > 20.f) return 1.f;
-    float e = expf(x), n = e * (e + 2.f), d = 1.f / (n + 2.f);
-    float t = n * d, omt2 = 4.f * (n + 1.f) * d * d;
-    return t + x * omt2 * (e / (1.f + e));
+    const float e = __expf(fminf(x, 20.f)), n = e * (e + 2.f), d = __builtin_amdgcn_rcpf(n + 2.f);
+    const float t = n * d, omt2 = 4.f * (n + 1.f) * d * d;
+    return t + x * omt2 * (e * __builtin_amdgcn_rcpf(1.f + e));
 }
 
 // dtype dispatch for extern "C" entry points

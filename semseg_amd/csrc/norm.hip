@@ -254,29 +254,76 @@ extern "C" int ss_bn_eval_stats(const float* running_mean, const float* running_
     return 0;
 }
 
+// Row walkers of the BatchNorm kernels: a thread keeps ONE 8-channel chunk (so mean / rstd / gamma / beta / coefficients are
+// loaded once, folded into scale + shift) and walks rows with a fixed stride, 4 rows of loads in flight per step.
+struct BnWalk { int cpb, rpb; };
+// 8 consecutive elements in storage dtype (converted where used: four rows in flight cost 4 registers each, not 8)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+    bf16x8 v;
+    __device__ __forceinline__ void load(const bf16* p) { v = *(const bf16x8*)p; }
+    __device__ __forceinline__ float get(int e) const { return (float)v[e]; }
+};
+template <> struct Raw8<float> {
+    floatx4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const floatx4*)p; b = *(const floatx4*)(p + 4); }
+    __device__ __forceinline__ float get(int e) const { return e < 4 ? a[e & 3] : b[e & 3]; }
+};                       // chunk lanes x row lanes of a 256-thread workgroup (col_geom)
+__device__ __forceinline__ int64_t bn_image_of(int64_t row, int64_t rows_per_image, int rpi_shift) {
+    return rpi_shift >= 0 ? row >> rpi_shift : row / rows_per_image;
+}
+static inline int pow2_shift(int64_t v) { return (v > 0 && (v & (v - 1)) == 0) ? __builtin_ctzll((unsigned long long)v) : -1; }
+
 // y[r] = res[r] + mask[b,c] * act(gamma * (z - mean) * rstd + beta);   act: 0 none, 1 Mish
-template <typename T>
+template <typename T, int ACT, bool MASK, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, int64_t ldz, const float* __restrict__ stats,
         const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, int64_t ldr,
-        const float* __restrict__ mask, int64_t rows_per_image, T* __restrict__ y, int64_t ldy, int64_t rows, int C, int act) {
-    const int chunks = C / 8;
-    const int64_t total = rows * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / chunks; const int c = (int)(i % chunks) * 8;
-        F8 v = load8(z + r * ldz + c), mu = load8(stats + c), rs = load8(stats + C + c), g = load8(gamma + c), b = load8(beta + c), o;
+        const float* __restrict__ mask, int64_t rows_per_image, int rpi_shift, T* __restrict__ y, int64_t ldy, int64_t rows, int C, BnWalk w) {
+    const int chunks = C / 8, t = threadIdx.x, ch = t % w.cpb, rl = t / w.cpb;
+    if (rl >= w.rpb) return;
+    for (int cbase = 0; cbase < chunks; cbase += w.cpb) {
+        const int chunk = cbase + ch;
+        if (chunk >= chunks) continue;
+        const int c = chunk * 8;
+        F8 sc, sh;
+        { F8 mu = load8(stats + c), rs = load8(stats + C + c), g = load8(gamma + c), b = load8(beta + c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float u = (v.v[e] - mu.v[e]) * rs.v[e] * g.v[e] + b.v[e];
-            o.v[e] = act == 1 ? mish_f(u) : u;
+          for (int e = 0; e < 8; ++e) { sc.v[e] = rs.v[e] * g.v[e]; sh.v[e] = b.v[e] - mu.v[e] * sc.v[e]; } }
+        const int64_t stride = (int64_t)gridDim.x * w.rpb;
+        for (int64_t r0 = (int64_t)blockIdx.x * w.rpb + rl; r0 < rows; r0 += 4 * stride) {
+            Raw8<T> v[4], q[4]; F8 m[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r = r0 + j * stride;
+                if (r < rows) {
+                    v[j].load(z + r * ldz + c);
+                    if (RES) q[j].load(res + r * ldr + c);
+                    if (MASK) m[j] = load8(mask + bn_image_of(r, rows_per_image, rpi_shift) * C + c);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r = r0 + j * stride;
+                if (r < rows) {
+                    F8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float u = fmaf(v[j].get(e), sc.v[e], sh.v[e]);
+                        if (ACT == 1) u = mish_f(u);
+                        if (MASK) u *= m[j].v[e];
+                        if (RES) u += q[j].get(e);
+                        o.v[e] = u;
+                    }
+                    store8(y + r * ldy + c, o);
+                }
+            }
         }
-        if (mask) { F8 m = load8(mask + (r / rows_per_image) * C + c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o.v[e] *= m.v[e]; }
-        if (res) { F8 q = load8(res + r * ldr + c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o.v[e] += q.v[e]; }
-        store8(y + r * ldy + c, o);
     }
+}
+
+static inline int bn_walk_blocks(int64_t rows, int rpb) {
+    int64_t b = cdiv(rows, (int64_t)rpb * 4);
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
 extern "C" int ss_bn_apply(int dtype, const void* z, int64_t ldz, const float* stats, const float* gamma, const float* beta,
@@ -285,33 +332,100 @@ extern "C" int ss_bn_apply(int dtype, const void* z, int64_t ldz, const float* s
     SS_CHECK(z && stats && gamma && beta && y && rows > 0 && C > 0 && C % 8 == 0, "ss_bn_apply: bad arguments (C=%d)", C);
     SS_CHECK(ldz >= C && ldy >= C && ldz % 8 == 0 && ldy % 8 == 0 && (!res || (ldr >= C && ldr % 8 == 0)), "ss_bn_apply: bad leading dimensions");
     SS_CHECK(!mask || rows_per_image > 0, "ss_bn_apply: rows_per_image required with a mask");
-    int64_t total = rows * (C / 8);
-    int blocks = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
-    SS_DISPATCH(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)z, ldz, stats, gamma, beta,
-                                          (const T*)res, ldr, mask, rows_per_image, (T*)y, ldy, rows, C, act));
+    SS_CHECK(act == 0 || act == 1, "ss_bn_apply: act must be 0 (none) or 1 (Mish)");
+    ColGeom g = col_geom(rows, C);
+    BnWalk w{g.cpb, g.rpb};
+    const int blocks = bn_walk_blocks(rows, g.rpb), sh = pow2_shift(rows_per_image);
+#define SS_BN_APPLY(ACT, MASK, RES) hipLaunchKernelGGL((bn_apply_kernel<T, ACT, MASK, RES>), dim3(blocks), dim3(256), 0, stream, (const T*)z, ldz, \
+        stats, gamma, beta, (const T*)res, ldr, mask, rows_per_image, sh, (T*)y, ldy, rows, C, w)
+    SS_DISPATCH(dtype, {
+        if (act) { if (mask) { if (res) SS_BN_APPLY(1, true, true); else SS_BN_APPLY(1, true, false); }
+                   else { if (res) SS_BN_APPLY(1, false, true); else SS_BN_APPLY(1, false, false); } }
+        else { if (mask) { if (res) SS_BN_APPLY(0, true, true); else SS_BN_APPLY(0, true, false); }
+               else { if (res) SS_BN_APPLY(0, false, true); else SS_BN_APPLY(0, false, false); } }
+    });
+#undef SS_BN_APPLY
     SS_LAUNCH_CHECK();
     return 0;
 }
 
-// backward, pass 1: g = dy * mask * act'(u);  partial sums of g and g * xhat
-template <typename T> struct BnBwdF {
-    static constexpr int K = 2;
-    const T* dy; int64_t ldd; const T* z; int64_t ldz; const float* stats; const float* gamma; const float* beta;
-    const float* mask; int64_t rows_per_image; int C; int act;
-    __device__ void operator()(int64_t row, int c0, float (&acc)[2][8]) const {
-        F8 d = load8(dy + row * ldd + c0), v = load8(z + row * ldz + c0), mu = load8(stats + c0), rs = load8(stats + C + c0);
-        F8 g = load8(gamma + c0), b = load8(beta + c0), m;
-        if (mask) m = load8(mask + (row / rows_per_image) * C + c0);
+// backward.  g = dy * mask * act'(u), u = xhat * gamma + beta.
+//   pass 1: partial[b][0][c] = sum g, partial[b][1][c] = sum g * xhat over the rows of workgroup b (fixed order)
+//   pass 2: dz = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat))
+// PASS2 selects which; both recompute g from dy and z (10 bytes per element in total, nothing extra stored by the forward).
+template <typename T, int ACT, bool MASK, bool PASS2>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const T* __restrict__ dy, int64_t ldd, const T* __restrict__ z, int64_t ldz,
+        const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
+        int64_t rows_per_image, int rpi_shift, const float* __restrict__ coef, T* __restrict__ dz, int64_t ldo,
+        float* __restrict__ partial, int64_t rows, int C, BnWalk w) {
+    __shared__ float red[PASS2 ? 1 : 256 * 8];
+    const int chunks = C / 8, t = threadIdx.x, ch = t % w.cpb, rl = t / w.cpb;
+    const bool rowlane = rl < w.rpb;
+    for (int cbase = 0; cbase < chunks; cbase += w.cpb) {
+        const int chunk = cbase + ch, c = chunk * 8;
+        const bool live = rowlane && chunk < chunks;
+        float acc[2][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float xh = (v.v[e] - mu.v[e]) * rs.v[e];
-            float gg = d.v[e];
-            if (mask) gg *= m.v[e];
-            if (act == 1) gg *= mish_grad(xh * g.v[e] + b.v[e]);
-            acc[0][e] += gg; acc[1][e] += gg * xh;
+        for (int e = 0; e < 8; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+        if (live) {
+            F8 xs, xo, gm, bt, k0, k1, k2;             // xhat = z * xs + xo;  dz = k0 * g + k1 + xhat * k2
+            { F8 mu = load8(stats + c), rs = load8(stats + C + c);
+              gm = load8(gamma + c); bt = load8(beta + c);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { xs.v[e] = rs.v[e]; xo.v[e] = -mu.v[e] * rs.v[e]; }
+              if (PASS2) { F8 c1 = load8(coef + c), c2 = load8(coef + C + c);
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) { k0.v[e] = gm.v[e] * rs.v[e]; k1.v[e] = -k0.v[e] * c1.v[e]; k2.v[e] = -k0.v[e] * c2.v[e]; } } }
+            const int64_t stride = (int64_t)gridDim.x * w.rpb;
+            for (int64_t r0 = (int64_t)blockIdx.x * w.rpb + rl; r0 < rows; r0 += 4 * stride) {
+                Raw8<T> d[4], v[4]; F8 m[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t r = r0 + j * stride;
+                    if (r < rows) {
+                        d[j].load(dy + r * ldd + c); v[j].load(z + r * ldz + c);
+                        if (MASK) m[j] = load8(mask + bn_image_of(r, rows_per_image, rpi_shift) * C + c);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t r = r0 + j * stride;
+                    if (r < rows) {
+                        F8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xh = fmaf(v[j].get(e), xs.v[e], xo.v[e]);
+                            float gg = d[j].get(e);
+                            if (MASK) gg *= m[j].v[e];
+                            if (ACT == 1) gg *= mish_grad(fmaf(xh, gm.v[e], bt.v[e]));
+                            if (PASS2) o.v[e] = fmaf(k0.v[e], gg, fmaf(xh, k2.v[e], k1.v[e]));
+                            else { acc[0][e] += gg; acc[1][e] = fmaf(gg, xh, acc[1][e]); }
+                        }
+                        if (PASS2) store8(dz + r * ldo + c, o);
+                    }
+                }
+            }
+        }
+        if (!PASS2) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[t * 8 + e] = acc[k][e];
+                __syncthreads();
+                if (rl == 0 && chunk < chunks) {
+                    float* dst = partial + ((int64_t)blockIdx.x * 2 + k) * C + c;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float s = 0.f;
+                        for (int j = 0; j < w.rpb; ++j) s += red[(j * w.cpb + ch) * 8 + e];
+                        dst[e] = s;
+                    }
+                }
+            }
         }
     }
-};
+}
 
 // dgb[0][c] = dgamma = sum g*xhat ; dgb[1][c] = dbeta = sum g ; coef[0][c] = mean g, coef[1][c] = mean g*xhat (0 in eval mode)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int C, int64_t n, int training,
@@ -334,29 +448,6 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     coef[C + c] = training ? (float)(q / (double)n) : 0.f;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const T* __restrict__ dy, int64_t ldd, const T* __restrict__ z, int64_t ldz,
-        const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
-        int64_t rows_per_image, const float* __restrict__ coef, T* __restrict__ dz, int64_t ldo, int64_t rows, int C, int act) {
-    const int chunks = C / 8;
-    const int64_t total = rows * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / chunks; const int c = (int)(i % chunks) * 8;
-        F8 d = load8(dy + r * ldd + c), v = load8(z + r * ldz + c), mu = load8(stats + c), rs = load8(stats + C + c);
-        F8 g = load8(gamma + c), b = load8(beta + c), c1 = load8(coef + c), c2 = load8(coef + C + c), m, o;
-        if (mask) m = load8(mask + (r / rows_per_image) * C + c);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float xh = (v.v[e] - mu.v[e]) * rs.v[e];
-            float gg = d.v[e];
-            if (mask) gg *= m.v[e];
-            if (act == 1) gg *= mish_grad(xh * g.v[e] + b.v[e]);
-            o.v[e] = g.v[e] * rs.v[e] * (gg - c1.v[e] - xh * c2.v[e]);
-        }
-        store8(dz + r * ldo + c, o);
-    }
-}
-
 // workspace: nb*2*C floats (partials) followed by 2*C floats (coefficients)
 extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, int64_t ldz, const float* stats, const float* gamma,
                          const float* beta, const float* mask, int64_t rows_per_image, int training, void* dz, int64_t ldo,
@@ -364,20 +455,26 @@ extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, 
     SS_CHECK(dy && z && stats && gamma && beta && dz && dgamma_dbeta && workspace && rows > 0 && C > 0 && C % 8 == 0, "ss_bn_bwd: bad arguments");
     SS_CHECK(ldd >= C && ldz >= C && ldo >= C && ldd % 8 == 0 && ldz % 8 == 0 && ldo % 8 == 0, "ss_bn_bwd: bad leading dimensions");
     SS_CHECK(!mask || rows_per_image > 0, "ss_bn_bwd: rows_per_image required with a mask");
+    SS_CHECK(act == 0 || act == 1, "ss_bn_bwd: act must be 0 (none) or 1 (Mish)");
     ColGeom g = col_geom(rows, C);
     SS_CHECK(ws_bytes >= ((int64_t)g.nb * 2 * C + 2 * C) * 4, "ss_bn_bwd: workspace too small");
     float* coef = workspace + (int64_t)g.nb * 2 * C;
-    int64_t total = rows * (C / 8);
-    int blocks = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+    BnWalk w{g.cpb, g.rpb};
+    const int blocks2 = bn_walk_blocks(rows, g.rpb), sh = pow2_shift(rows_per_image);
+#define SS_BN_BWD(ACT, MASK, P2, GRID) hipLaunchKernelGGL((bn_bwd_kernel<T, ACT, MASK, P2>), dim3(GRID), dim3(256), 0, stream, (const T*)dy, ldd, \
+        (const T*)z, ldz, stats, gamma, beta, mask, rows_per_image, sh, coef, (T*)dz, ldo, workspace, rows, C, w)
+#define SS_BN_BWD_PASS(P2, GRID) do { \
+        if (act) { if (mask) SS_BN_BWD(1, true, P2, GRID); else SS_BN_BWD(1, false, P2, GRID); } \
+        else { if (mask) SS_BN_BWD(0, true, P2, GRID); else SS_BN_BWD(0, false, P2, GRID); } } while (0)
     SS_DISPATCH(dtype, {
-        BnBwdF<T> f{(const T*)dy, ldd, (const T*)z, ldz, stats, gamma, beta, mask, rows_per_image, C, act};
-        hipLaunchKernelGGL((colreduce_partial_kernel<BnBwdF<T>>), dim3(g.nb, 1), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
+        SS_BN_BWD_PASS(false, g.nb);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, g.nb, C, rows, training, dgamma_dbeta, coef);
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL((bn_bwd_dz_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)dy, ldd, (const T*)z, ldz, stats, gamma, beta,
-                           mask, rows_per_image, coef, (T*)dz, ldo, rows, C, act);
+        SS_BN_BWD_PASS(true, blocks2);
     });
+#undef SS_BN_BWD_PASS
+#undef SS_BN_BWD
     SS_LAUNCH_CHECK();
     return 0;
 }
