@@ -105,27 +105,40 @@ __global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* _
             for (int ks = 0; ks < D / 16; ++ks)
                 s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, img_slot<CH>(kt * 32 + j, ks * 2 + h)), qf[ks], s[kt], 0, 0, 0);
         }
-        float mx = -INFINITY;
+        // online softmax on the raw scores (c > 0 folds scale and log2 e into the exponent's fma); the key-tail mask, the
+        // rescale of the output accumulator and nothing else are taken only when a lane needs them (wave-uniform branches)
+        if (key0 + 64 > Nk) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + kt * 32 + acc_row(r, h) >= Nk) s[kt][r] = -INFINITY;
+        }
+        float mx = s[0][0];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = (key0 + kt * 32 + acc_row(r, h) < Nk) ? s[kt][r] * c : -INFINITY;
-                s[kt][r] = v; mx = fmaxf(mx, v);
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+        const float mn = fmaxf(m, mx);
+        if (__builtin_amdgcn_ballot_w64(mn > m)) {          // some query's maximum moved: rescale (alpha = 1 for the others)
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+            m = mn;
+        }
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c, -mn)), p1 = __builtin_amdgcn_exp2f(fmaf(s[kt][r + 1], c, -mn));
+                s[kt][r] = p0; s[kt][r + 1] = p1; ps0 += p0; ps1 += p1;
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx), alpha = exp2f(m - mn);
-        m = mn;
-        float ps = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { float p = exp2f(s[kt][r] - mn); s[kt][r] = p; ps += p; }
-        l = l * alpha + ps;
-#pragma unroll
-        for (int t = 0; t < D / 32; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        l += ps0 + ps1;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dq_bf16_kernel(const bf16
         qf[s] = *(const bf16x8*)(q + ((int64_t)b * N + qrow) * C + hd * D + 16 * s + 8 * h);
         dof[s] = *(const bf16x8*)(dout + ((int64_t)b * N + qrow) * C + hd * D + 16 * s + 8 * h);
     }
-    const float ls = lse[(int64_t)(b * heads + hd) * Np + qrow], dl = delta[(int64_t)(b * heads + hd) * Np + qrow];
+    const float ls = lse[(int64_t)(b * heads + hd) * Np + qrow], dls = delta[(int64_t)(b * heads + hd) * Np + qrow] * scale;
     const bf16* kbase = kv + (int64_t)b * Nk * 2 * C + hd * D;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     bf16x8 rk[NCH], rv[NCH];
@@ -212,9 +225,14 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dq_bf16_kernel(const bf16
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, sl), dof[ks], dp, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = (key0 + kt * 32 + acc_row(r, h) < Nk) ? exp2f(s[r] * c - ls) : 0.f;
-                s[r] = p * (dp[r] - dl) * scale;
+            for (int r = 0; r < 16; ++r) {                  // dS = P (dP - delta) scale, P = 2^(s c - lse): fma, v_exp, fma, mul
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -ls));
+                s[r] = p * fmaf(dp[r], scale, -dls);
+            }
+            if (key0 + 64 > Nk) {                           // keys past Nk (zero rows of the staged tile) take no part
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + kt * 32 + acc_row(r, h) >= Nk) s[r] = 0.f;
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -295,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dkv_bf16_kernel(const bf1
         __syncthreads();
         for (int q0 = qbeg; q0 < qend; q0 += 64) {
             const bool more = q0 + 64 < qend;
+            const bool tail = q0 + 64 > qend || (blockIdx.x + 1) * 128 > Nk;     // workgroup-uniform
             if (more) gload(q0 + 64);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
@@ -314,10 +333,14 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dkv_bf16_kernel(const bf1
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * g + e;
-                        const bool ok = kvalid && (q0 + ql + e < qend);        // qend <= N; rows past the split belong to the next slab
-                        const float p = ok ? exp2f(s[r] * c - l4[e]) : 0.f;
+                        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -l4[e]));
                         s[r] = p;
                         dp[r] = p * (dp[r] - d4[e]) * scale;
+                    }
+                    if (tail) {                                 // keys past Nk, queries past the split (they belong to the next slab; qend <= N)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (!(kvalid && q0 + ql + e < qend)) { s[4 * g + e] = 0.f; dp[4 * g + e] = 0.f; }
                     }
                 }
 #pragma unroll
