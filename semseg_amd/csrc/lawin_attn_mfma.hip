@@ -91,14 +91,14 @@ __global__ __launch_bounds__(128) void lawin_attn_fwd_mfma_kernel(LawinAttnArgs 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[qt][ks], s[kt], 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[kt][r] *= a.c2; mx = fmaxf(mx, s[kt][r]); }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.c2;      // c2 > 0: scale and log2 e go into the exponent's fma
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { float p = exp2f(s[kt][r] - mx); s[kt][r] = p; l += p; }
+            for (int r = 0; r < 16; ++r) { float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], a.c2, -mx)); s[kt][r] = p; l += p; }
         l += __shfl_xor(l, 32, 64);
         floatx16 oacc[TD];
 #pragma unroll
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(128) void lawin_attn_bwd_mfma_kernel(LawinAttnArgs 
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][ks], dof[qt][ks], dp, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = exp2f(s[r] * a.c2 - ls[qt]) * (dp[r] - dl[qt]) * a.scale;
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], a.c2, -ls[qt])) * fmaf(dp[r], a.scale, -dl[qt] * a.scale);
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 bf16x8 df = cvt_frag<bf16>(s, st);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(128) void lawin_attn_bwd_mfma_kernel(LawinAttnArgs 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
-                    const float p = exp2f(s[r] * a.c2 - l4[e]);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[r], a.c2, -l4[e]));
                     s[r] = p;
                     dp[r] = p * (dp[r] - d4[e]) * a.scale;
                 }
