@@ -14,6 +14,7 @@
 //                       mostly padding; the op is bandwidth / VALU bound), one wave per (window, head), lane = query
 //                       (and lane = key for the dphi/dg pass), phi/g/theta/dY rows broadcast from LDS.
 #include "common.h"
+#include <initializer_list>
 #include "colreduce.h"
 
 // bf16 MFMA window attention for head dims 16 / 32 / 64 (lawin_attn_mfma.hip)
@@ -198,7 +199,34 @@ __global__ __launch_bounds__(256) void lawin_mix_wgrad_kernel(const T* __restric
 // ------------------------------------------------------------------ window attention, one wave per (window, head)
 // theta / y / dy / dtheta: image layout rows (b*H + 8i+qy)*W + 8j+qx, `inter` channels (ld given);
 // pg / dpg: window layout rows w*64 + k, 2*inter channels (phi | g).
-template <typename T, int D>
+// D consecutive elements <-> fp32 registers: one 4 / 8 / 16-byte access when VEC (host-checked alignment), else element-wise
+template <typename T, int D, bool VEC>
+__device__ __forceinline__ void load_d(const T* p, float (&o)[D]) {
+    if constexpr (VEC && D > 1 && D * sizeof(T) <= 16) {
+        typedef T V __attribute__((ext_vector_type(D)));
+        const V v = *(const V*)p;
+#pragma unroll
+        for (int d = 0; d < D; ++d) o[d] = to_f(v[d]);
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) o[d] = to_f(p[d]);
+    }
+}
+template <typename T, int D, bool VEC>
+__device__ __forceinline__ void store_d(T* p, const float (&o)[D]) {
+    if constexpr (VEC && D > 1 && D * sizeof(T) <= 16) {
+        typedef T V __attribute__((ext_vector_type(D)));
+        V v;
+#pragma unroll
+        for (int d = 0; d < D; ++d) v[d] = from_f<T>(o[d]);
+        *(V*)p = v;
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) p[d] = from_f<T>(o[d]);
+    }
+}
+
+template <typename T, int D, bool VEC>
 __global__ __launch_bounds__(256) void lawin_attn_fwd_kernel(const T* __restrict__ theta, int64_t ldt, const T* __restrict__ pg,
         T* __restrict__ y, int64_t ldy, float* __restrict__ lse, WinGeom g, int inter, int heads, float c2) {
     extern __shared__ __attribute__((aligned(16))) float shm[];     // per wave: phi[64][D] | g[64][D]
@@ -209,31 +237,53 @@ __global__ __launch_bounds__(256) void lawin_attn_fwd_kernel(const T* __restrict
     const int j = (int)(wi % g.nw); int64_t q = wi / g.nw; const int i = (int)(q % g.nh); const int64_t b = q / g.nh;
     float* ph = shm + wave * (2 * 64 * D); float* gg = ph + 64 * D;
     const T* prow = pg + (wi * 64 + lane) * (2 * (int64_t)inter) + hd * D;
-#pragma unroll
-    for (int d = 0; d < D; ++d) { ph[lane * D + d] = to_f(prow[d]); gg[lane * D + d] = to_f(prow[inter + d]); }
     const int64_t row = (b * g.H + 8 * i + (lane >> 3)) * g.W + 8 * j + (lane & 7);
     float th[D], acc[D];
+    {
+        float a[D], c[D];
+        load_d<T, D, VEC>(prow, a); load_d<T, D, VEC>(prow + inter, c); load_d<T, D, VEC>(theta + row * ldt + hd * D, th);
 #pragma unroll
-    for (int d = 0; d < D; ++d) { th[d] = to_f(theta[row * ldt + hd * D + d]) * c2; acc[d] = 0.f; }
+        for (int d = 0; d < D; ++d) { ph[lane * D + d] = a[d]; gg[lane * D + d] = c[d]; th[d] *= c2; acc[d] = 0.f; }
+    }
     __builtin_amdgcn_wave_barrier();
     float m = -INFINITY, l = 0.f;
+    if constexpr (D <= 16) {
+        // two passes over the 64 keys with the scores in registers: 2 D fma + max + sub + v_exp + add per pair
+        float sc[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s = fmaf(th[d], ph[k * D + d], s);
+            sc[k] = s; m = fmaxf(m, s);
+        }
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            const float p = __builtin_amdgcn_exp2f(sc[k] - m);
+            l += p;
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] = fmaf(p, gg[k * D + d], acc[d]);
+        }
+    } else {
 #pragma unroll 2
-    for (int k = 0; k < 64; ++k) {
-        float s = 0.f;
+        for (int k = 0; k < 64; ++k) {
+            float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) s += th[d] * ph[k * D + d];
-        const float mn = fmaxf(m, s), alpha = exp2f(m - mn), p = exp2f(s - mn);
-        m = mn; l = l * alpha + p;
+            for (int d = 0; d < D; ++d) s += th[d] * ph[k * D + d];
+            const float mn = fmaxf(m, s), alpha = __builtin_amdgcn_exp2f(m - mn), p = __builtin_amdgcn_exp2f(s - mn);
+            m = mn; l = l * alpha + p;
 #pragma unroll
-        for (int d = 0; d < D; ++d) acc[d] = acc[d] * alpha + p * gg[k * D + d];
+            for (int d = 0; d < D; ++d) acc[d] = acc[d] * alpha + p * gg[k * D + d];
+        }
     }
     const float inv = 1.f / l;
 #pragma unroll
-    for (int d = 0; d < D; ++d) y[row * ldy + hd * D + d] = from_f<T>(acc[d] * inv);
+    for (int d = 0; d < D; ++d) acc[d] *= inv;
+    store_d<T, D, VEC>(y + row * ldy + hd * D, acc);
     lse[(wi * heads + hd) * 64 + lane] = m + log2f(l);
 }
 
-template <typename T, int D>
+template <typename T, int D, bool VEC>
 __global__ __launch_bounds__(256) void lawin_attn_bwd_kernel(const T* __restrict__ theta, int64_t ldt, const T* __restrict__ pg,
         const T* __restrict__ y, int64_t ldy, const T* __restrict__ dy, int64_t lddy, const float* __restrict__ lse,
         T* __restrict__ dtheta, int64_t lddt, T* __restrict__ dpg, WinGeom g, int inter, int heads, float c2, float scale) {
@@ -249,64 +299,57 @@ __global__ __launch_bounds__(256) void lawin_attn_bwd_kernel(const T* __restrict
     const int64_t row = (b * g.H + 8 * i + (lane >> 3)) * g.W + 8 * j + (lane & 7);
     float delta = 0.f;
     const float mylse = lse[(wi * heads + hd) * 64 + lane];
+    float th[D], dq[D], pk[D], gk[D];
+    {
+        float yv[D];
+        load_d<T, D, VEC>(prow, pk); load_d<T, D, VEC>(prow + inter, gk);
+        load_d<T, D, VEC>(theta + row * ldt + hd * D, th); load_d<T, D, VEC>(dy + row * lddy + hd * D, dq);
+        load_d<T, D, VEC>(y + row * ldy + hd * D, yv);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        ph[lane * D + d] = to_f(prow[d]); gg[lane * D + d] = to_f(prow[inter + d]);
-        const float tq = to_f(theta[row * ldt + hd * D + d]) * c2, dq = to_f(dy[row * lddy + hd * D + d]);
-        ts[lane * D + d] = tq; ds_[lane * D + d] = dq;
-        delta += dq * to_f(y[row * ldy + hd * D + d]);
+        for (int d = 0; d < D; ++d) {
+            th[d] *= c2;
+            ph[lane * D + d] = pk[d]; gg[lane * D + d] = gk[d]; ts[lane * D + d] = th[d]; ds_[lane * D + d] = dq[d];
+            delta = fmaf(dq[d], yv[d], delta);
+        }
     }
     ls[lane] = mylse; dl[lane] = delta;
     __builtin_amdgcn_wave_barrier();
     {   // pass A, lane = query: dtheta_q = scale * sum_k p (dp - delta) phi_k
-        float th[D], dq[D], acc[D];
+        float acc[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) { th[d] = ts[lane * D + d]; dq[d] = ds_[lane * D + d]; acc[d] = 0.f; }
-#pragma unroll 2
+        for (int d = 0; d < D; ++d) acc[d] = 0.f;
+#pragma unroll 4
         for (int k = 0; k < 64; ++k) {
-            float s = 0.f, dp = 0.f;
+            float s = -mylse, dp = -delta;
 #pragma unroll
-            for (int d = 0; d < D; ++d) { s += th[d] * ph[k * D + d]; dp += dq[d] * gg[k * D + d]; }
-            const float w = exp2f(s - mylse) * (dp - delta);
+            for (int d = 0; d < D; ++d) { s = fmaf(th[d], ph[k * D + d], s); dp = fmaf(dq[d], gg[k * D + d], dp); }
+            const float w = __builtin_amdgcn_exp2f(s) * dp;
 #pragma unroll
-            for (int d = 0; d < D; ++d) acc[d] += w * ph[k * D + d];
+            for (int d = 0; d < D; ++d) acc[d] = fmaf(w, ph[k * D + d], acc[d]);
         }
 #pragma unroll
-        for (int d = 0; d < D; ++d) dtheta[row * lddt + hd * D + d] = from_f<T>(acc[d] * scale);
+        for (int d = 0; d < D; ++d) acc[d] *= scale;
+        store_d<T, D, VEC>(dtheta + row * lddt + hd * D, acc);
     }
     T* drow = dpg + (wi * 64 + lane) * (2 * (int64_t)inter) + hd * D;
-    {   // pass B1, lane = key: dg_k = sum_q p dY_q
-        float pk[D], acc[D];
+    {   // pass B, lane = key: dg_k = sum_q p dY_q ; dphi_k = scale * sum_q p (dp - delta_q) theta_q   (ts holds theta*c2: undone at the end)
+        float ag[D], ap[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) { pk[d] = ph[lane * D + d]; acc[d] = 0.f; }
-#pragma unroll 2
+        for (int d = 0; d < D; ++d) { ag[d] = 0.f; ap[d] = 0.f; }
+#pragma unroll 4
         for (int qq = 0; qq < 64; ++qq) {
-            float s = 0.f;
+            float s = -ls[qq], dp = -dl[qq];
 #pragma unroll
-            for (int d = 0; d < D; ++d) s += pk[d] * ts[qq * D + d];
-            const float p = exp2f(s - ls[qq]);
+            for (int d = 0; d < D; ++d) { s = fmaf(pk[d], ts[qq * D + d], s); dp = fmaf(gk[d], ds_[qq * D + d], dp); }
+            const float p = __builtin_amdgcn_exp2f(s), w = p * dp;
 #pragma unroll
-            for (int d = 0; d < D; ++d) acc[d] += p * ds_[qq * D + d];
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) drow[inter + d] = from_f<T>(acc[d]);
-    }
-    {   // pass B2, lane = key: dphi_k = scale * sum_q p (dp - delta_q) theta_q      (ts holds theta*c2: undo c2 at the end)
-        float pk[D], gk[D], acc[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) { pk[d] = ph[lane * D + d]; gk[d] = gg[lane * D + d]; acc[d] = 0.f; }
-#pragma unroll 2
-        for (int qq = 0; qq < 64; ++qq) {
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < D; ++d) { s += pk[d] * ts[qq * D + d]; dp += gk[d] * ds_[qq * D + d]; }
-            const float w = exp2f(s - ls[qq]) * (dp - dl[qq]);
-#pragma unroll
-            for (int d = 0; d < D; ++d) acc[d] += w * ts[qq * D + d];
+            for (int d = 0; d < D; ++d) { ag[d] = fmaf(p, ds_[qq * D + d], ag[d]); ap[d] = fmaf(w, ts[qq * D + d], ap[d]); }
         }
         const float f = scale / c2;
 #pragma unroll
-        for (int d = 0; d < D; ++d) drow[d] = from_f<T>(acc[d] * f);
+        for (int d = 0; d < D; ++d) ap[d] *= f;
+        store_d<T, D, VEC>(drow, ap);
+        store_d<T, D, VEC>(drow + inter, ag);
     }
 }
 
@@ -399,7 +442,12 @@ extern "C" int ss_lawin_mix_wgrad(int dtype, const void* G, const void* dwin, fl
     return 0;
 }
 
-template <typename T, int D>
+template <typename T, int D> static bool attn_vec_ok(std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+    for (const void* p : ptrs) if ((uintptr_t)p % (D * sizeof(T))) return false;
+    for (int64_t l : lds) if (l % D) return false;
+    return true;
+}
+template <typename T, int D, bool VEC>
 static int attn_fwd_launch(const T* theta, int64_t ldt, const T* pg, T* y, int64_t ldy, float* lse, WinGeom g, int inter, int heads,
                            hipStream_t stream) {
     const size_t per_wave = (size_t)2 * 64 * D * sizeof(float);
@@ -407,13 +455,13 @@ static int attn_fwd_launch(const T* theta, int64_t ldt, const T* pg, T* y, int64
     const float scale = 1.f / sqrtf((float)D);
     dim3 grid((unsigned)((int64_t)g.B * g.nh * g.nw), (unsigned)cdiv(heads, waves));
     if (waves * per_wave > 65536)
-        SS_HIP(hipFuncSetAttribute((const void*)lawin_attn_fwd_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(waves * per_wave)));
-    hipLaunchKernelGGL((lawin_attn_fwd_kernel<T, D>), grid, dim3(64 * waves), waves * per_wave, stream, theta, ldt, pg, y, ldy, lse, g, inter, heads,
+        SS_HIP(hipFuncSetAttribute((const void*)lawin_attn_fwd_kernel<T, D, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(waves * per_wave)));
+    hipLaunchKernelGGL((lawin_attn_fwd_kernel<T, D, VEC>), grid, dim3(64 * waves), waves * per_wave, stream, theta, ldt, pg, y, ldy, lse, g, inter, heads,
                        scale * 1.4426950408889634f);
     SS_LAUNCH_CHECK();
     return 0;
 }
-template <typename T, int D>
+template <typename T, int D, bool VEC>
 static int attn_bwd_launch(const T* theta, int64_t ldt, const T* pg, const T* y, int64_t ldy, const T* dy, int64_t lddy, const float* lse,
                            T* dtheta, int64_t lddt, T* dpg, WinGeom g, int inter, int heads, hipStream_t stream) {
     const size_t per_wave = (size_t)(4 * 64 * D + 128) * sizeof(float);
@@ -421,16 +469,16 @@ static int attn_bwd_launch(const T* theta, int64_t ldt, const T* pg, const T* y,
     const float scale = 1.f / sqrtf((float)D);
     dim3 grid((unsigned)((int64_t)g.B * g.nh * g.nw), (unsigned)cdiv(heads, waves));
     if (waves * per_wave > 65536)
-        SS_HIP(hipFuncSetAttribute((const void*)lawin_attn_bwd_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(waves * per_wave)));
-    hipLaunchKernelGGL((lawin_attn_bwd_kernel<T, D>), grid, dim3(64 * waves), waves * per_wave, stream, theta, ldt, pg, y, ldy, dy, lddy, lse, dtheta,
+        SS_HIP(hipFuncSetAttribute((const void*)lawin_attn_bwd_kernel<T, D, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(waves * per_wave)));
+    hipLaunchKernelGGL((lawin_attn_bwd_kernel<T, D, VEC>), grid, dim3(64 * waves), waves * per_wave, stream, theta, ldt, pg, y, ldy, dy, lddy, lse, dtheta,
                        lddt, dpg, g, inter, heads, scale * 1.4426950408889634f, scale);
     SS_LAUNCH_CHECK();
     return 0;
 }
-#define SS_D_SWITCH(D, CALL) \
-    switch (D) { case 1: { constexpr int DD = 1; CALL; } break; case 2: { constexpr int DD = 2; CALL; } break; case 4: { constexpr int DD = 4; CALL; } break; \
-                 case 8: { constexpr int DD = 8; CALL; } break; case 16: { constexpr int DD = 16; CALL; } break; \
-                 case 32: { constexpr int DD = 32; CALL; } break; case 64: { constexpr int DD = 64; CALL; } break; \
+#define SS_D_CASE(N, ...) case N: { constexpr int DD = N; __VA_ARGS__; } break;
+#define SS_D_SWITCH(D, ...) \
+    switch (D) { SS_D_CASE(1, __VA_ARGS__) SS_D_CASE(2, __VA_ARGS__) SS_D_CASE(4, __VA_ARGS__) SS_D_CASE(8, __VA_ARGS__) \
+                 SS_D_CASE(16, __VA_ARGS__) SS_D_CASE(32, __VA_ARGS__) SS_D_CASE(64, __VA_ARGS__) \
                  default: return ss_fail(-1, "lawin attention: unsupported head dim %d", D); }
 
 // lse: [windows][heads][64] fp32
@@ -443,7 +491,10 @@ extern "C" int ss_lawin_attn_fwd(int dtype, const void* theta, int64_t ldt, cons
     int rc = 0;
     if (dtype == SS_BF16 && lawin_attn_mfma_ok(D, theta, ldt, pg, inter, y, ldy, nullptr, 0, nullptr, 0))
         return lawin_attn_fwd_mfma(theta, ldt, pg, y, ldy, lse, B, H, W, inter, heads, stream);
-    SS_DISPATCH(dtype, SS_D_SWITCH(D, rc = (attn_fwd_launch<T, DD>((const T*)theta, ldt, (const T*)pg, (T*)y, ldy, lse, g, inter, heads, stream))));
+    SS_DISPATCH(dtype, SS_D_SWITCH(D, {
+        if (attn_vec_ok<T, DD>({theta, pg, y}, {ldt, ldy, (int64_t)inter}))
+            rc = attn_fwd_launch<T, DD, true>((const T*)theta, ldt, (const T*)pg, (T*)y, ldy, lse, g, inter, heads, stream);
+        else rc = attn_fwd_launch<T, DD, false>((const T*)theta, ldt, (const T*)pg, (T*)y, ldy, lse, g, inter, heads, stream); }));
     return rc;
 }
 extern "C" int ss_lawin_attn_bwd(int dtype, const void* theta, int64_t ldt, const void* pg, const void* y, int64_t ldy, const void* dy,
@@ -457,7 +508,11 @@ extern "C" int ss_lawin_attn_bwd(int dtype, const void* theta, int64_t ldt, cons
     int rc = 0;
     if (dtype == SS_BF16 && lawin_attn_mfma_ok(D, theta, ldt, pg, inter, y, ldy, dy, lddy, dtheta, lddt) && aligned16(dpg))
         return lawin_attn_bwd_mfma(theta, ldt, pg, y, ldy, dy, lddy, lse, dtheta, lddt, dpg, B, H, W, inter, heads, stream);
-    SS_DISPATCH(dtype, SS_D_SWITCH(D, rc = (attn_bwd_launch<T, DD>((const T*)theta, ldt, (const T*)pg, (const T*)y, ldy, (const T*)dy, lddy, lse,
-                                                                   (T*)dtheta, lddt, (T*)dpg, g, inter, heads, stream))));
+    SS_DISPATCH(dtype, SS_D_SWITCH(D, {
+        if (attn_vec_ok<T, DD>({theta, pg, y, dy, dtheta, dpg}, {ldt, ldy, lddy, lddt, (int64_t)inter}))
+            rc = attn_bwd_launch<T, DD, true>((const T*)theta, ldt, (const T*)pg, (const T*)y, ldy, (const T*)dy, lddy, lse, (T*)dtheta, lddt,
+                                              (T*)dpg, g, inter, heads, stream);
+        else rc = attn_bwd_launch<T, DD, false>((const T*)theta, ldt, (const T*)pg, (const T*)y, ldy, (const T*)dy, lddy, lse, (T*)dtheta, lddt,
+                                                (T*)dpg, g, inter, heads, stream); }));
     return rc;
 }
