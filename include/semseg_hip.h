@@ -53,6 +53,7 @@ int ss_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* 
                      float* rstd, int64_t rows, int C, float eps, hipStream_t stream);
 /* dgamma/dbeta: one [2,C] fp32 buffer (dbeta == dgamma + C); workspace >= 1024*2*C floats. */
 int ss_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                     const void* res /* optional [rows,C]: added to dx (gradient of the residual path around the norm) */,
                      void* dx, float* dgamma, float* dbeta, int64_t rows, int C, float* workspace, int64_t ws_bytes,
                      hipStream_t stream);
 

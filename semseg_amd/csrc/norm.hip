@@ -6,90 +6,142 @@
 
 // ------------------------------------------------------------------ LayerNorm
 // One row is handled by `lpr` lanes (power of two), NCH chunks of 8 channels per lane.
+// 8 consecutive elements in storage dtype (converted where used: four rows in flight cost 4 registers each, not 8)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+    bf16x8 v;
+    __device__ __forceinline__ void load(const bf16* p) { v = *(const bf16x8*)p; }
+    __device__ __forceinline__ float get(int e) const { return (float)v[e]; }
+};
+template <> struct Raw8<float> {
+    floatx4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const floatx4*)p; b = *(const floatx4*)(p + 4); }
+    __device__ __forceinline__ float get(int e) const { return e < 4 ? a[e & 3] : b[e & 3]; }
+};                       // chunk lanes x row lanes of a 256-thread workgroup (col_geom)
+
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
         const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
         int64_t rows, int C, int lpr, float eps) {
     const int lane = threadIdx.x & 63, lig = lane & (lpr - 1), rpw = 64 / lpr;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t r0 = wave * rpw; r0 < rows; r0 += nwaves * rpw) {
-        const int64_t r = r0 + lane / lpr;
-        const bool rok = r < rows;
-        F8 v[NCH]; float s = 0.f;
+    F8 gm[NCH], bt[NCH];                                   // this lane's channels never change: load the affine once
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            int c = (lig + j * lpr) * 8;
-            if (rok && c < C) { v[j] = load8(x + r * C + c);
+    for (int j = 0; j < NCH; ++j) {
+        const int c = (lig + j * lpr) * 8;
+        gm[j] = c < C ? load8(gamma + c) : zero8(); bt[j] = c < C ? load8(beta + c) : zero8();
+    }
+    const float invC = 1.f / C;
+    for (int64_t r0 = wave * rpw; r0 < rows; r0 += 2 * nwaves * rpw) {      // two rows per lane group in flight
+        int64_t r[2]; bool rok[2];
+        Raw8<T> raw[2][NCH];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += v[j].v[e]; }
-            else v[j] = zero8();
+        for (int u = 0; u < 2; ++u) {
+            r[u] = r0 + u * nwaves * rpw + lane / lpr;
+            rok[u] = r[u] < rows;
+            const int64_t rr = rok[u] ? r[u] : 0;             // clamped: the loads stay unconditional
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) { const int c = (lig + j * lpr) * 8; raw[u][j].load(x + rr * C + (c < C ? c : 0)); }
         }
-        const float mu = group_sum(s, lpr) / C;
-        float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            int c = (lig + j * lpr) * 8;
-            if (c < C) {
+        for (int u = 0; u < 2; ++u) {
+            F8 v[NCH]; float s = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float d = v[j].v[e] - mu; q += d * d; } }
-        }
-        const float rs = rsqrtf(group_sum(q, lpr) / C + eps);
-        if (!rok) continue;
-        if (lig == 0) { mean[r] = mu; rstd[r] = rs; }
+            for (int j = 0; j < NCH; ++j) {
+                const float live = (lig + j * lpr) * 8 < C ? 1.f : 0.f;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            int c = (lig + j * lpr) * 8;
-            if (c < C) {
-                F8 g = load8(gamma + c), b = load8(beta + c), o;
+                for (int e = 0; e < 8; ++e) { v[j].v[e] = raw[u][j].get(e) * live; s += v[j].v[e]; }
+            }
+            const float mu = group_sum(s, lpr) * invC;
+            float q = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o.v[e] = (v[j].v[e] - mu) * rs * g.v[e] + b.v[e];
-                store8(y + r * C + c, o);
+            for (int j = 0; j < NCH; ++j) {
+                const float live = (lig + j * lpr) * 8 < C ? 1.f : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (v[j].v[e] - mu) * live; v[j].v[e] = d; q = fmaf(d, d, q); }
+            }
+            const float rs = rsqrtf(group_sum(q, lpr) * invC + eps);
+            if (rok[u]) {
+                if (lig == 0) { mean[r[u]] = mu; rstd[r[u]] = rs; }
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const int c = (lig + j * lpr) * 8;
+                    if (c < C) {
+                        F8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o.v[e] = fmaf(v[j].v[e] * rs, gm[j].v[e], bt[j].v[e]);
+                        store8(y + r[u] * C + c, o);
+                    }
+                }
             }
         }
     }
 }
 
-// dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat));  per-block partials of dgamma = sum dy*xhat, dbeta = sum dy
-template <typename T, int NCH>
+// dx = res + rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat));  per-block partials of dgamma = sum dy*xhat, dbeta = sum dy.
+// `res` (optional) is the gradient arriving over the residual connection around the normalised branch: adding it here saves
+// the separate elementwise pass.  Two rows per lane group are in flight per step; gamma is loaded once per lane.
+template <typename T, int NCH, bool RES>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-        const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+        const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma, const T* __restrict__ res,
         T* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C, int lpr) {
     extern __shared__ float sh[];                 // [groups][2][C]
     const int lane = threadIdx.x & 63, lig = lane & (lpr - 1), rpw = 64 / lpr;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     float dg[NCH][8], db[NCH][8];
+    F8 gm[NCH];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j)
+    for (int j = 0; j < NCH; ++j) {
+        const int c = (lig + j * lpr) * 8;
+        gm[j] = c < C ? load8(gamma + c) : zero8();
 #pragma unroll
         for (int e = 0; e < 8; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; }
-    for (int64_t r0 = wave * rpw; r0 < rows; r0 += nwaves * rpw) {
-        const int64_t r = r0 + lane / lpr;
-        const bool rok = r < rows;
-        const float mu = rok ? mean[r] : 0.f, rs = rok ? rstd[r] : 0.f;
-        F8 xh[NCH], gy[NCH]; float s1 = 0.f, s2 = 0.f;
+    }
+    for (int64_t r0 = wave * rpw; r0 < rows; r0 += 2 * nwaves * rpw) {
+        int64_t r[2]; bool rok[2]; float mu[2], rs[2];
+        Raw8<T> xv[2][NCH], dv[2][NCH], qv[2][NCH];
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            int c = (lig + j * lpr) * 8;
-            if (rok && c < C) {
-                F8 xv = load8(x + r * C + c), dv = load8(dy + r * C + c), g = load8(gamma + c);
+        for (int u = 0; u < 2; ++u) {
+            r[u] = r0 + u * nwaves * rpw + lane / lpr;
+            rok[u] = r[u] < rows;
+            const int64_t rr = rok[u] ? r[u] : 0;                 // clamped: the loads stay unconditional
+            mu[u] = mean[rr]; rs[u] = rstd[rr];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c = (lig + j * lpr) * 8, cc = c < C ? c : 0;
+                xv[u][j].load(x + rr * C + cc); dv[u][j].load(dy + rr * C + cc);
+                if (RES) qv[u][j].load(res + rr * C + cc);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            F8 xh[NCH], gy[NCH]; float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c = (lig + j * lpr) * 8;
+                const float live = (rok[u] && c < C) ? 1.f : 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float h = (xv.v[e] - mu) * rs;
-                    dg[j][e] += dv.v[e] * h; db[j][e] += dv.v[e];
-                    float t = dv.v[e] * g.v[e];
-                    xh[j].v[e] = h; gy[j].v[e] = t; s1 += t; s2 += t * h;
+                    const float h = (xv[u][j].get(e) - mu[u]) * rs[u], d = dv[u][j].get(e) * live;
+                    dg[j][e] = fmaf(d, h, dg[j][e]); db[j][e] += d;
+                    const float t = d * gm[j].v[e];
+                    xh[j].v[e] = h; gy[j].v[e] = t; s1 += t; s2 = fmaf(t, h, s2);
                 }
-            } else { xh[j] = zero8(); gy[j] = zero8(); }
-        }
-        s1 = group_sum(s1, lpr) / C; s2 = group_sum(s2, lpr) / C;
-        if (!rok) continue;
+            }
+            s1 = group_sum(s1, lpr) / C; s2 = group_sum(s2, lpr) / C;
+            if (rok[u]) {
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            int c = (lig + j * lpr) * 8;
-            if (c < C) { F8 o;
+                for (int j = 0; j < NCH; ++j) {
+                    const int c = (lig + j * lpr) * 8;
+                    if (c < C) { F8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o.v[e] = rs * (gy[j].v[e] - s1 - xh[j].v[e] * s2);
-                store8(dx + r * C + c, o); }
+                        for (int e = 0; e < 8; ++e) {
+                            o.v[e] = rs[u] * (gy[j].v[e] - s1 - xh[j].v[e] * s2);
+                            if (RES) o.v[e] += qv[u][j].get(e);
+                        }
+                        store8(dx + r[u] * C + c, o); }
+                }
+            }
         }
     }
     // fixed-order block reduction of the per-lane column partials
@@ -134,8 +186,8 @@ extern "C" int ss_layernorm_fwd(int dtype, const void* x, const float* gamma, co
 // workspace: SS_LN_BWD_BLOCKS * 2 * C floats
 #define SS_LN_BWD_BLOCKS 1024
 extern "C" int ss_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                                void* dx, float* dgamma, float* dbeta, int64_t rows, int C, float* workspace, int64_t ws_bytes,
-                                hipStream_t stream) {
+                                const void* res, void* dx, float* dgamma, float* dbeta, int64_t rows, int C, float* workspace,
+                                int64_t ws_bytes, hipStream_t stream) {
     int lpr, nch;
     SS_CHECK(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && rows > 0, "ss_layernorm_bwd: bad arguments");
     SS_CHECK(ln_geom(C, &lpr, &nch) == 0, "ss_layernorm_bwd: C=%d must be a multiple of 8 and <= 1024", C);
@@ -144,10 +196,13 @@ extern "C" int ss_layernorm_bwd(int dtype, const void* dy, const void* x, const 
     int blocks = (int)(cdiv(waves, 4) < SS_LN_BWD_BLOCKS ? cdiv(waves, 4) : SS_LN_BWD_BLOCKS);
     SS_CHECK(ws_bytes >= (int64_t)blocks * 2 * C * 4, "ss_layernorm_bwd: workspace too small");
     size_t shm = (size_t)4 * (64 / lpr) * 2 * C * sizeof(float);
+#define SS_LN_BWD(NCH, RES) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, RES>), dim3(blocks), dim3(256), shm, stream, (const T*)dy, (const T*)x, \
+        mean, rstd, gamma, (const T*)res, (T*)dx, workspace, rows, C, lpr)
     SS_DISPATCH(dtype, {
-        if (nch == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 1>), dim3(blocks), dim3(256), shm, stream, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, workspace, rows, C, lpr);
-        else hipLaunchKernelGGL((layernorm_bwd_kernel<T, 2>), dim3(blocks), dim3(256), shm, stream, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, workspace, rows, C, lpr);
+        if (nch == 1) { if (res) SS_LN_BWD(1, true); else SS_LN_BWD(1, false); }
+        else { if (res) SS_LN_BWD(2, true); else SS_LN_BWD(2, false); }
     });
+#undef SS_LN_BWD
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(2 * C, 8), 1), dim3(256), 0, stream, workspace, blocks, 2 * C, 1.f, dgamma, 0);
     SS_LAUNCH_CHECK();
@@ -257,18 +312,6 @@ extern "C" int ss_bn_eval_stats(const float* running_mean, const float* running_
 // Row walkers of the BatchNorm kernels: a thread keeps ONE 8-channel chunk (so mean / rstd / gamma / beta / coefficients are
 // loaded once, folded into scale + shift) and walks rows with a fixed stride, 4 rows of loads in flight per step.
 struct BnWalk { int cpb, rpb; };
-// 8 consecutive elements in storage dtype (converted where used: four rows in flight cost 4 registers each, not 8)
-template <typename T> struct Raw8;
-template <> struct Raw8<bf16> {
-    bf16x8 v;
-    __device__ __forceinline__ void load(const bf16* p) { v = *(const bf16x8*)p; }
-    __device__ __forceinline__ float get(int e) const { return (float)v[e]; }
-};
-template <> struct Raw8<float> {
-    floatx4 a, b;
-    __device__ __forceinline__ void load(const float* p) { a = *(const floatx4*)p; b = *(const floatx4*)(p + 4); }
-    __device__ __forceinline__ float get(int e) const { return e < 4 ? a[e & 3] : b[e & 3]; }
-};                       // chunk lanes x row lanes of a 256-thread workgroup (col_geom)
 __device__ __forceinline__ int64_t bn_image_of(int64_t row, int64_t rows_per_image, int rpi_shift) {
     return rpi_shift >= 0 ? row >> rpi_shift : row / rows_per_image;
 }

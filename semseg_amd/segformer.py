@@ -201,12 +201,10 @@ class BlockFn(_ParamFn):
         N = h * w
         g = dx3 if keep_m is None else ops.rowscale(dx3, keep_m, N)
         dn2, Gm = mlp_backward(_sub(P, 'mlp.'), S['Sm'], g, B, h, w)
-        d, dgb2 = ops.layernorm_bwd(dn2, S['x2'], S['m2'], S['r2'], P['norm2.weight'])
-        dx2 = ops.add(d, dx3)
+        dx2, dgb2 = ops.layernorm_bwd(dn2, S['x2'], S['m2'], S['r2'], P['norm2.weight'], res=dx3)
         g = dx2 if keep_a is None else ops.rowscale(dx2, keep_a, N)
         dn1, Ga = attn_backward(_sub(P, 'attn.'), S['Sa'], g, B, h, w, head, sr)
-        d, dgb1 = ops.layernorm_bwd(dn1, S['x'], S['m1'], S['r1'], P['norm1.weight'])
-        dx = ops.add(d, dx2)
+        dx, dgb1 = ops.layernorm_bwd(dn1, S['x'], S['m1'], S['r1'], P['norm1.weight'], res=dx2)
         G = {'norm1.weight': dgb1[0], 'norm1.bias': dgb1[1], 'norm2.weight': dgb2[0], 'norm2.bias': dgb2[1]}
         G.update(_pre(Ga, 'attn.'))
         G.update(_pre(Gm, 'mlp.'))

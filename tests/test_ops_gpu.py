@@ -140,6 +140,10 @@ def test_layernorm(ops, dtype, rows, C):
     dx, dgb = ops.layernorm_bwd(dev(dy, dtype), dev(x, dtype), mean, rstd, dev(g))
     assert rel(dx, xr.grad) < _tol(dtype)
     assert rel(dgb[0], gr.grad) < 1e-4 and rel(dgb[1], br.grad) < 1e-4
+    res = rnd(rows, C, seed=4)                               # gradient of the residual path, added in the same pass
+    dx2, dgb2 = ops.layernorm_bwd(dev(dy, dtype), dev(x, dtype), mean, rstd, dev(g), res=dev(res, dtype))
+    assert rel(dx2, xr.grad + q(res, dtype)) < _tol(dtype)
+    assert float((dgb2 - dgb).abs().max()) == 0
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
