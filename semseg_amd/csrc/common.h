@@ -72,6 +72,22 @@ __device__ __forceinline__ F8 zero8() { F8 r;
     for (int i = 0; i < 8; ++i) r.v[i] = 0.f;
     return r; }
 
+// ---------------------------------------------------------------- division by a launch-invariant integer
+// Flat element indices are decomposed into (pixel, tap, channel chunk, ...) in every layout kernel; a hardware integer
+// division costs dozens of instructions (hundreds for 64-bit), so the divisors are turned into multiply + shift on the host.
+// Valid for dividends < 2^31.
+struct FastDiv { unsigned d, mul, sh; };
+static inline FastDiv fast_div(unsigned d) {
+    FastDiv f; f.d = d; f.mul = 0; f.sh = 0;
+    if (d > 1) {
+        unsigned lg = 31 - __builtin_clz(d); if (d & (d - 1)) ++lg;
+        const unsigned p = 31 + lg;
+        f.mul = (unsigned)(((1ull << p) + d - 1) / d); f.sh = p - 32;
+    }
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.sh); }
+
 // ---------------------------------------------------------------- wave helpers (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

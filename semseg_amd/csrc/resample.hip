@@ -5,19 +5,19 @@
 #include "common.h"
 
 // ------------------------------------------------------------------ im2col / col2im   (column order: ky, kx, c)
+// grid: (B*ho output rows, blocks over the wo * k*k * C/8 chunk items of a row)
 template <typename T>
-__global__ __launch_bounds__(256) void im2col_vec_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int H, int W, int C,
-                                                         int k, int s, int pad, int ho, int wo) {
-    const int chunks = C / 8, kk = k * k;
-    const int64_t total = (int64_t)B * ho * wo * kk * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % chunks) * 8; int64_t p = i / chunks;
-        const int tap = (int)(p % kk); p /= kk;
-        const int ox = (int)(p % wo); int64_t q = p / wo; const int oy = (int)(q % ho); const int64_t b = q / ho;
-        const int iy = oy * s - pad + tap / k, ix = ox * s - pad + tap % k;
-        F8 v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? load8(x + ((b * H + iy) * W + ix) * C + c) : zero8();
-        store8(col + p * ((int64_t)kk * C) + (int64_t)tap * C + c, v);
-    }
+__global__ __launch_bounds__(256) void im2col_vec_kernel(const T* __restrict__ x, T* __restrict__ col, int H, int W, int C,
+                                                         int k, int s, int pad, int ho, int wo, FastDiv dchunks, FastDiv dper, FastDiv dk) {
+    const unsigned chunks = dchunks.d, per = dper.d;                 // per = k*k*chunks items per output pixel
+    const unsigned idx = blockIdx.y * 256u + threadIdx.x;
+    if (idx >= (unsigned)wo * per) return;
+    const unsigned row = blockIdx.x, b = row / (unsigned)ho, oy = row - b * ho;
+    const unsigned ox = fdiv(idx, dper), rem = idx - ox * per, tap = fdiv(rem, dchunks), c = (rem - tap * chunks) * 8;
+    const unsigned ky = fdiv(tap, dk), kx = tap - ky * k;
+    const int iy = (int)(oy * s + ky) - pad, ix = (int)(ox * s + kx) - pad;
+    F8 v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? load8(x + (((int64_t)b * H + iy) * W + ix) * C + c) : zero8();
+    store8(col + ((int64_t)row * wo + ox) * ((int64_t)k * k * C) + (int64_t)tap * C + c, v);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_scalar_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int H, int W, int C,
@@ -35,31 +35,33 @@ __global__ __launch_bounds__(256) void im2col_scalar_kernel(const T* __restrict_
         col[i] = from_f<T>(v);
     }
 }
-// gather form: every input pixel sums the taps that read it (deterministic)
+// gather form: every input pixel sums the taps that read it (deterministic).  grid: (B*H input rows, blocks over W * C/8)
 template <typename T>
-__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ col, T* __restrict__ dx, int B, int H, int W, int C,
-                                                     int k, int s, int pad, int ho, int wo) {
-    const int chunks = C / 8, kk = k * k;
-    const int64_t total = (int64_t)B * H * W * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % chunks) * 8; int64_t p = i / chunks;
-        const int ix = (int)(p % W); int64_t q = p / W; const int iy = (int)(q % H); const int64_t b = q / H;
-        F8 acc = zero8();
-        for (int ky = 0; ky < k; ++ky) {
-            int ty = iy + pad - ky;
-            if (ty < 0 || ty % s) continue;
-            int oy = ty / s; if (oy >= ho) continue;
-            for (int kx = 0; kx < k; ++kx) {
-                int tx = ix + pad - kx;
-                if (tx < 0 || tx % s) continue;
-                int ox = tx / s; if (ox >= wo) continue;
-                F8 v = load8(col + ((b * ho + oy) * wo + ox) * ((int64_t)kk * C) + (int64_t)(ky * k + kx) * C + c);
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ col, T* __restrict__ dx, int H, int W, int C,
+                                                     int k, int s, int pad, int ho, int wo, FastDiv dchunks, FastDiv ds) {
+    const unsigned chunks = dchunks.d;
+    const unsigned idx = blockIdx.y * 256u + threadIdx.x;
+    if (idx >= (unsigned)W * chunks) return;
+    const unsigned row = blockIdx.x, b = row / (unsigned)H, iy = row - b * H;
+    const unsigned ix = fdiv(idx, dchunks), c = (idx - ix * chunks) * 8;
+    const int64_t kkC = (int64_t)k * k * C;
+    F8 acc = zero8();
+    for (int ky = 0; ky < k; ++ky) {
+        const int ty = (int)iy + pad - ky;
+        if (ty < 0) break;
+        const unsigned oy = fdiv((unsigned)ty, ds);
+        if (oy * s != (unsigned)ty || oy >= (unsigned)ho) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int tx = (int)ix + pad - kx;
+            if (tx < 0) break;
+            const unsigned ox = fdiv((unsigned)tx, ds);
+            if (ox * s != (unsigned)tx || ox >= (unsigned)wo) continue;
+            F8 v = load8(col + (((int64_t)b * ho + oy) * wo + ox) * kkC + (int64_t)(ky * k + kx) * C + c);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc.v[e] += v.v[e];
-            }
+            for (int e = 0; e < 8; ++e) acc.v[e] += v.v[e];
         }
-        store8(dx + p * C + c, acc);
     }
+    store8(dx + ((int64_t)row * W + ix) * C + c, acc);
 }
 
 extern "C" int ss_im2col(int dtype, const void* x, void* col, int B, int H, int W, int C, int k, int s, int pad, int Kp, hipStream_t stream) {
@@ -68,9 +70,11 @@ extern "C" int ss_im2col(int dtype, const void* x, void* col, int B, int H, int 
     SS_CHECK(ho > 0 && wo > 0 && Kp >= k * k * C, "ss_im2col: bad geometry");
     if (C % 8 == 0) {
         SS_CHECK(Kp == k * k * C, "ss_im2col: Kp must equal k*k*C when C is a multiple of 8");
-        int64_t total = (int64_t)B * ho * wo * k * k * (C / 8);
-        int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
-        SS_DISPATCH(dtype, hipLaunchKernelGGL((im2col_vec_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)x, (T*)col, B, H, W, C, k, s, pad, ho, wo));
+        const int64_t per_row = (int64_t)wo * k * k * (C / 8);
+        SS_CHECK(per_row < (1LL << 31) && cdiv(per_row, 256) < 65536 && (int64_t)B * ho < (1LL << 31), "ss_im2col: row too long");
+        dim3 grid((unsigned)(B * ho), (unsigned)cdiv(per_row, 256));
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((im2col_vec_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, (T*)col, H, W, C, k, s, pad, ho, wo,
+                                              fast_div(C / 8), fast_div(k * k * (C / 8)), fast_div(k)));
     } else {
         int64_t total = (int64_t)B * ho * wo * Kp;
         int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
@@ -83,9 +87,11 @@ extern "C" int ss_col2im(int dtype, const void* col, void* dx, int B, int H, int
     SS_CHECK(col && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && k > 0 && s > 0 && pad >= 0, "ss_col2im: bad arguments (C=%d)", C);
     const int ho = (H + 2 * pad - k) / s + 1, wo = (W + 2 * pad - k) / s + 1;
     SS_CHECK(ho > 0 && wo > 0, "ss_col2im: bad geometry");
-    int64_t total = (int64_t)B * H * W * (C / 8);
-    int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
-    SS_DISPATCH(dtype, hipLaunchKernelGGL((col2im_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)col, (T*)dx, B, H, W, C, k, s, pad, ho, wo));
+    const int64_t per_row = (int64_t)W * (C / 8);
+    SS_CHECK(per_row < (1LL << 31) && cdiv(per_row, 256) < 65536 && (int64_t)B * H < (1LL << 31), "ss_col2im: row too long");
+    dim3 grid((unsigned)(B * H), (unsigned)cdiv(per_row, 256));
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((col2im_kernel<T>), grid, dim3(256), 0, stream, (const T*)col, (T*)dx, H, W, C, k, s, pad, ho, wo,
+                                          fast_div(C / 8), fast_div(s)));
     SS_LAUNCH_CHECK();
     return 0;
 }
@@ -101,86 +107,128 @@ __device__ __forceinline__ LinTap lin_tap(int o, float scale, int in) {
     return t;
 }
 
+// grid: (B*ho output rows, blocks over the wo * chunks items of a row); the vertical tap is uniform per workgroup
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
-        int B, int hi, int wi, int ho, int wo, int C) {
+        int hi, int wi, int ho, int wo, FastDiv dchunks) {
     constexpr int W8 = VEC ? 8 : 1;
-    const int chunks = C / W8;
-    const float sh = (float)hi / ho, sw = (float)wi / wo;
-    const int64_t total = (int64_t)B * ho * wo * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % chunks) * W8; int64_t p = i / chunks;
-        const int ox = (int)(p % wo); int64_t q = p / wo; const int oy = (int)(q % ho); const int64_t b = q / ho;
-        const LinTap ty = lin_tap(oy, sh, hi), tx = lin_tap(ox, sw, wi);
-        const T* r0 = x + ((b * hi + ty.i0) * wi) * ldx + c;
-        const T* r1 = x + ((b * hi + ty.i1) * wi) * ldx + c;
-        if (VEC) {
-            F8 a = load8(r0 + tx.i0 * ldx), bq = load8(r0 + tx.i1 * ldx), cq = load8(r1 + tx.i0 * ldx), d = load8(r1 + tx.i1 * ldx), o;
+    const unsigned chunks = dchunks.d;
+    const unsigned idx = blockIdx.y * 256u + threadIdx.x;
+    if (idx >= (unsigned)wo * chunks) return;
+    const unsigned row = blockIdx.x, b = row / (unsigned)ho, oy = row - b * ho;
+    const unsigned ox = fdiv(idx, dchunks), c = (idx - ox * chunks) * W8;
+    const LinTap ty = lin_tap((int)oy, (float)hi / ho, hi), tx = lin_tap((int)ox, (float)wi / wo, wi);
+    const T* r0 = x + (((int64_t)b * hi + ty.i0) * wi) * ldx + c;
+    const T* r1 = x + (((int64_t)b * hi + ty.i1) * wi) * ldx + c;
+    T* dst = y + ((int64_t)row * wo + ox) * ldy + c;
+    if (VEC) {
+        F8 a = load8(r0 + tx.i0 * ldx), bq = load8(r0 + tx.i1 * ldx), cq = load8(r1 + tx.i0 * ldx), d = load8(r1 + tx.i1 * ldx), o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o.v[e] = ty.l0 * (tx.l0 * a.v[e] + tx.l1 * bq.v[e]) + ty.l1 * (tx.l0 * cq.v[e] + tx.l1 * d.v[e]);
-            store8(y + p * ldy + c, o);
-        } else {
-            float o = ty.l0 * (tx.l0 * to_f(r0[tx.i0 * ldx]) + tx.l1 * to_f(r0[tx.i1 * ldx])) +
-                      ty.l1 * (tx.l0 * to_f(r1[tx.i0 * ldx]) + tx.l1 * to_f(r1[tx.i1 * ldx]));
-            y[p * ldy + c] = from_f<T>(o);
-        }
+        for (int e = 0; e < 8; ++e) o.v[e] = ty.l0 * (tx.l0 * a.v[e] + tx.l1 * bq.v[e]) + ty.l1 * (tx.l0 * cq.v[e] + tx.l1 * d.v[e]);
+        store8(dst, o);
+    } else {
+        float o = ty.l0 * (tx.l0 * to_f(r0[tx.i0 * ldx]) + tx.l1 * to_f(r0[tx.i1 * ldx])) +
+                  ty.l1 * (tx.l0 * to_f(r1[tx.i0 * ldx]) + tx.l1 * to_f(r1[tx.i1 * ldx]));
+        dst[0] = from_f<T>(o);
     }
 }
 
-// gather-form backward: dx[b,iy,ix,:] = sum over the output pixels whose taps touch (iy,ix)
+// Narrow tensors (the nc-class logits): a thread computes ALL channels of one output pixel into an LDS image of the
+// workgroup's 256 pixels, which then leaves as one contiguous run (dense rows: ldy == C).  grid: (B*ho rows, blocks of 256 px)
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_narrow_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
+        int hi, int wi, int ho, int wo, int C) {
+    extern __shared__ __attribute__((aligned(16))) char nsm[];
+    T* img = (T*)nsm;
+    const unsigned row = blockIdx.x, b = row / (unsigned)ho, oy = row - b * ho;
+    const unsigned ox0 = blockIdx.y * 256u, ox = ox0 + threadIdx.x;
+    const unsigned npx = min(256u, (unsigned)wo - ox0);
+    if (ox < (unsigned)wo) {
+        const LinTap ty = lin_tap((int)oy, (float)hi / ho, hi), tx = lin_tap((int)ox, (float)wi / wo, wi);
+        const T* r0 = x + (((int64_t)b * hi + ty.i0) * wi) * ldx;
+        const T* r1 = x + (((int64_t)b * hi + ty.i1) * wi) * ldx;
+        const T *p00 = r0 + tx.i0 * ldx, *p01 = r0 + tx.i1 * ldx, *p10 = r1 + tx.i0 * ldx, *p11 = r1 + tx.i1 * ldx;
+        for (int c = 0; c < C; ++c) {
+            const float o = ty.l0 * (tx.l0 * to_f(p00[c]) + tx.l1 * to_f(p01[c])) + ty.l1 * (tx.l0 * to_f(p10[c]) + tx.l1 * to_f(p11[c]));
+            img[threadIdx.x * C + c] = from_f<T>(o);
+        }
+    }
+    __syncthreads();
+    T* dst = y + ((int64_t)row * wo + ox0) * C;
+    const unsigned bytes = npx * C * (unsigned)sizeof(T);
+    if ((((uintptr_t)dst | bytes) & 15) == 0) {
+        for (unsigned i = threadIdx.x * 16u; i < bytes; i += 256u * 16u) *(floatx4*)((char*)dst + i) = *(const floatx4*)(nsm + i);
+    } else {
+        for (unsigned i = threadIdx.x; i < npx * C; i += 256u) dst[i] = img[i];
+    }
+}
+
+// gather-form backward: dx[b,iy,ix,:] = sum over the output pixels whose taps touch (iy,ix).
+// grid: (B*hi input rows, blocks over wi * chunks); the output-row range and its weights are uniform per workgroup.
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, int64_t ldy, T* __restrict__ dx, int64_t ldx,
-        int B, int hi, int wi, int ho, int wo, int C, int accumulate) {
+        int hi, int wi, int ho, int wo, FastDiv dchunks, int accumulate) {
     constexpr int W8 = VEC ? 8 : 1;
-    const int chunks = C / W8;
+    const unsigned chunks = dchunks.d;
+    const unsigned idx = blockIdx.y * 256u + threadIdx.x;
+    if (idx >= (unsigned)wi * chunks) return;
+    const unsigned row = blockIdx.x, b = row / (unsigned)hi;
+    const int iy = (int)(row - b * hi);
+    const int ix = (int)fdiv(idx, dchunks), c = (int)(idx - (unsigned)ix * chunks) * W8;
     const float sh = (float)hi / ho, sw = (float)wi / wo;
-    const int64_t total = (int64_t)B * hi * wi * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % chunks) * W8; int64_t p = i / chunks;
-        const int ix = (int)(p % wi); int64_t q = p / wi; const int iy = (int)(q % hi); const int64_t b = q / hi;
-        int oy0 = (int)floorf((iy - 0.5f) / sh - 0.5f) - 1, oy1 = (int)ceilf((iy + 1.5f) / sh - 0.5f) + 1;
-        int ox0 = (int)floorf((ix - 0.5f) / sw - 0.5f) - 1, ox1 = (int)ceilf((ix + 1.5f) / sw - 0.5f) + 1;
-        oy0 = max(oy0, 0); ox0 = max(ox0, 0); oy1 = min(oy1, ho - 1); ox1 = min(ox1, wo - 1);
-        float acc[W8];
+    int oy0 = (int)floorf((iy - 0.5f) / sh - 0.5f) - 1, oy1 = (int)ceilf((iy + 1.5f) / sh - 0.5f) + 1;
+    int ox0 = (int)floorf((ix - 0.5f) / sw - 0.5f) - 1, ox1 = (int)ceilf((ix + 1.5f) / sw - 0.5f) + 1;
+    oy0 = max(oy0, 0); ox0 = max(ox0, 0); oy1 = min(oy1, ho - 1); ox1 = min(ox1, wo - 1);
+    float acc[W8];
 #pragma unroll
-        for (int e = 0; e < W8; ++e) acc[e] = 0.f;
-        for (int oy = oy0; oy <= oy1; ++oy) {
-            const LinTap ty = lin_tap(oy, sh, hi);
-            const float wy = (ty.i0 == iy ? ty.l0 : 0.f) + (ty.i1 == iy ? ty.l1 : 0.f);
-            if (wy == 0.f) continue;
-            for (int ox = ox0; ox <= ox1; ++ox) {
-                const LinTap tx = lin_tap(ox, sw, wi);
-                const float wx = (tx.i0 == ix ? tx.l0 : 0.f) + (tx.i1 == ix ? tx.l1 : 0.f);
-                if (wx == 0.f) continue;
-                const T* src = dy + ((b * ho + oy) * wo + ox) * ldy + c;
-                if (VEC) { F8 v = load8(src);
+    for (int e = 0; e < W8; ++e) acc[e] = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        const LinTap ty = lin_tap(oy, sh, hi);
+        const float wy = (ty.i0 == iy ? ty.l0 : 0.f) + (ty.i1 == iy ? ty.l1 : 0.f);
+        if (wy == 0.f) continue;
+        const T* srow = dy + (((int64_t)b * ho + oy) * wo) * ldy + c;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            const LinTap tx = lin_tap(ox, sw, wi);
+            const float wx = (tx.i0 == ix ? tx.l0 : 0.f) + (tx.i1 == ix ? tx.l1 : 0.f);
+            if (wx == 0.f) continue;
+            const T* src = srow + (int64_t)ox * ldy;
+            if (VEC) { F8 v = load8(src);
 #pragma unroll
-                    for (int e = 0; e < W8; ++e) acc[e] += wy * wx * v.v[e]; }
-                else acc[0] += wy * wx * to_f(src[0]);
-            }
+                for (int e = 0; e < W8; ++e) acc[e] += wy * wx * v.v[e]; }
+            else acc[0] += wy * wx * to_f(src[0]);
         }
-        T* dst = dx + p * ldx + c;
-        if (VEC) { F8 o;
-            if (accumulate) { o = load8(dst);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o.v[e] += acc[e]; }
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o.v[e] = acc[e]; }
-            store8(dst, o);
-        } else dst[0] = from_f<T>(accumulate ? to_f(dst[0]) + acc[0] : acc[0]);
     }
+    T* dst = dx + ((int64_t)row * wi + ix) * ldx + c;
+    if (VEC) { F8 o;
+        if (accumulate) { o = load8(dst);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] += acc[e]; }
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] = acc[e]; }
+        store8(dst, o);
+    } else dst[0] = from_f<T>(accumulate ? to_f(dst[0]) + acc[0] : acc[0]);
 }
 
 extern "C" int ss_bilinear_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
                                hipStream_t stream) {
     SS_CHECK(x && y && B > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && C > 0 && ldx >= C && ldy >= C, "ss_bilinear_fwd: bad arguments");
     const bool vec = C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y);
-    int64_t total = (int64_t)B * ho * wo * (vec ? C / 8 : C);
-    int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+    const int chunks = vec ? C / 8 : C;
+    const int64_t per_row = (int64_t)wo * chunks;
+    SS_CHECK(per_row < (1LL << 31) && cdiv(per_row, 256) < 65536 && (int64_t)B * ho < (1LL << 31), "ss_bilinear_fwd: row too long");
+    const int esz = dtype == SS_BF16 ? 2 : 4;
+    if (!vec && ldy == C && C <= 32) {
+        dim3 grid((unsigned)(B * ho), (unsigned)cdiv(wo, 256));
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((bilinear_fwd_narrow_kernel<T>), grid, dim3(256), 256 * C * esz, stream, (const T*)x, ldx, (T*)y, hi, wi,
+                                              ho, wo, C));
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
+    dim3 grid((unsigned)(B * ho), (unsigned)cdiv(per_row, 256));
     SS_DISPATCH(dtype, {
-        if (vec) hipLaunchKernelGGL((bilinear_fwd_kernel<T, true>), dim3(blocks), dim3(256), 0, stream, (const T*)x, ldx, (T*)y, ldy, B, hi, wi, ho, wo, C);
-        else hipLaunchKernelGGL((bilinear_fwd_kernel<T, false>), dim3(blocks), dim3(256), 0, stream, (const T*)x, ldx, (T*)y, ldy, B, hi, wi, ho, wo, C);
+        if (vec) hipLaunchKernelGGL((bilinear_fwd_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)x, ldx, (T*)y, ldy, hi, wi, ho, wo, fast_div(chunks));
+        else hipLaunchKernelGGL((bilinear_fwd_kernel<T, false>), grid, dim3(256), 0, stream, (const T*)x, ldx, (T*)y, ldy, hi, wi, ho, wo, fast_div(chunks));
     });
     SS_LAUNCH_CHECK();
     return 0;
@@ -189,11 +237,13 @@ extern "C" int ss_bilinear_bwd(int dtype, const void* dy, int64_t ldy, void* dx,
                                int accumulate, hipStream_t stream) {
     SS_CHECK(dy && dx && B > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && C > 0 && ldx >= C && ldy >= C, "ss_bilinear_bwd: bad arguments");
     const bool vec = C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && aligned16(dx) && aligned16(dy);
-    int64_t total = (int64_t)B * hi * wi * (vec ? C / 8 : C);
-    int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+    const int chunks = vec ? C / 8 : C;
+    const int64_t per_row = (int64_t)wi * chunks;
+    SS_CHECK(per_row < (1LL << 31) && cdiv(per_row, 256) < 65536 && (int64_t)B * hi < (1LL << 31), "ss_bilinear_bwd: row too long");
+    dim3 grid((unsigned)(B * hi), (unsigned)cdiv(per_row, 256));
     SS_DISPATCH(dtype, {
-        if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true>), dim3(blocks), dim3(256), 0, stream, (const T*)dy, ldy, (T*)dx, ldx, B, hi, wi, ho, wo, C, accumulate);
-        else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false>), dim3(blocks), dim3(256), 0, stream, (const T*)dy, ldy, (T*)dx, ldx, B, hi, wi, ho, wo, C, accumulate);
+        if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)dy, ldy, (T*)dx, ldx, hi, wi, ho, wo, fast_div(chunks), accumulate);
+        else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false>), grid, dim3(256), 0, stream, (const T*)dy, ldy, (T*)dx, ldx, hi, wi, ho, wo, fast_div(chunks), accumulate);
     });
     SS_LAUNCH_CHECK();
     return 0;
