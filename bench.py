@@ -120,9 +120,21 @@ def kernel_table(trace):
     for name, args, e0, e1 in trace:
         ms = e0.elapsed_time(e1)
         bound, work = entry_work(name, args)
-        t = tab.setdefault(name, {'calls': 0, 'ms': 0.0, 'work': 0.0, 'bound': bound, 'known': True})
+        t = tab.setdefault(name, {'calls': 0, 'ms': 0.0, 'work': 0.0, 'bound': bound, 'known': True, 'bytes': 0.0, 'ideal_ms': 0.0})
         t['calls'] += 1
         t['ms'] += ms
+        if name.startswith('ss_gemm') and work is not None:
+            # algorithmic bytes (every operand touched once) and the roofline time of THIS shape: most launches of the family
+            # are projections with K, N of a few hundred, bounded by HBM rather than by the matrix cores
+            a = args
+            if name == 'ss_gemm_nt':
+                M, N, K = a[8:11]
+                byt = (M * K + N * K + M * N * (2 if a[12] else 1)) * _sz(a[0])
+            else:
+                M, N, K = a[7:10]
+                byt = (K * M + K * N) * _sz(a[0]) + M * N * 4
+            t['bytes'] += byt
+            t['ideal_ms'] += 1e3 * max(work / (MFMA_BF16_PEAK_TFLOPS * 1e12), byt / (HBM_PEAK_GBS * 1e9))
         if work is None:
             t['known'] = False
         else:
@@ -162,13 +174,13 @@ def shape_table(trace):
               f"{fl / per / 1e9:7.1f} TFLOP/s {byt / per / 1e6:7.0f} GB/s", file=sys.stderr)
 
 
-def roofline_from_table(tab):
+def roofline_from_table(tab, traffic_ok=False):
     fam = {}
     for name, t in tab.items():
         key = 'gemm' if name.startswith('ss_gemm') else name
-        f = fam.setdefault(key, {'calls': 0, 'ms': 0.0, 'work': 0.0, 'bound': t['bound'], 'known': True})
-        for k in ('calls', 'ms', 'work'):
-            f[k] += t[k]
+        f = fam.setdefault(key, {'calls': 0, 'ms': 0.0, 'work': 0.0, 'bound': t['bound'], 'known': True, 'bytes': 0.0, 'ideal_ms': 0.0})
+        for k in ('calls', 'ms', 'work', 'bytes', 'ideal_ms'):
+            f[k] += t.get(k, 0.0)
         f['known'] = f['known'] and t['known']
     name, f = max(fam.items(), key=lambda kv: kv[1]['ms'])
     out = {'kernel': 'gemm_kernel (ss_gemm_nt + ss_gemm_tn)' if name == 'gemm' else name, 'bound': f['bound'],
@@ -184,6 +196,16 @@ def roofline_from_table(tab):
     else:
         out.update(achieved=None, peak=None, unit=None, frac=None)
     out['traffic'] = None
+    if name == 'gemm' and f['ideal_ms'] > 0:
+        # per-launch roofline: sum over launches of max(flops / MFMA peak, algorithmic bytes / HBM peak), over the measured time
+        out['algorithmic_bytes_per_launch'] = f['bytes'] / f['calls']
+        out['frac_of_per_shape_roofline'] = f['ideal_ms'] / f['ms']
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_hbm_traffic.json')
+        if traffic_ok and os.path.exists(pmc):
+            with open(pmc) as fh:
+                g = json.load(fh)['gemm_family']
+            out['traffic'] = g['hbm_bytes_per_launch']
+            out['traffic_source'] = 'profiles/r01_pmc_hbm_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this command)'
     return out
 
 
@@ -349,7 +371,9 @@ def main():
         trace, _lib.TRACE = _lib.TRACE, None
         if rank == 0:
             table = kernel_table(trace)
-            roof = roofline_from_table(table)
+            # the committed PMC traffic figure was collected on the default headline configuration only
+            default_cfg = a.variant == 'B2' and a.embed == 512 and a.batch == 16 and a.size == 1024 and a.dtype == 'bf16'
+            roof = roofline_from_table(table, traffic_ok=default_cfg)
             if a.shapes:
                 shape_table(trace)
     fence()
