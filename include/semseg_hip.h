@@ -156,10 +156,12 @@ int ss_lawin_pool_bwd(int dtype, const float* dG8, const float* dG4, const float
 int ss_lawin_gather_bwd(int dtype, const void* dctx, float* dG, int B, int H, int W, int C, int r, hipStream_t stream);
 /* LawinAttn.position_mixing (:44-46,62-69): out[w,p',c] = x[w,p',c] + sum_p Wm[head(c)][p'][p] x[w,p,c] + bm[head(c)][p'];
  * x gathered from G (xwin NULL) or read window-ordered (G NULL); transpose != 0 applies Wm^T without bias (backward).
- * Wm: [heads][64][64] fp32, bm: [heads][64] fp32; out: [windows*64, C]. */
+ * Wm: [heads][64][64] fp32, bm: [heads][64] fp32; out: [windows*64, C].
+ * workspace (optional, ss_lawin_mix_workspace(heads) bytes): enables the bf16 matrix-core path (C % 128 == 0, C / heads in 8..128). */
+int64_t ss_lawin_mix_workspace(int heads);
 int ss_lawin_mix(int dtype, const void* G, const void* xwin, const float* Wm, const float* bm, void* out, int B, int H, int W,
-                 int C, int r, int heads, int transpose, hipStream_t stream);
-int64_t ss_lawin_mix_wgrad_workspace(int B, int H, int W, int heads);
+                 int C, int r, int heads, int transpose, void* workspace, int64_t ws_bytes, hipStream_t stream);
+int64_t ss_lawin_mix_wgrad_workspace(int B, int H, int W, int C, int heads);
 /* dWb: [heads][64][65] fp32 (64 weight columns, then the bias column) */
 int ss_lawin_mix_wgrad(int dtype, const void* G, const void* dwin, float* dWb, int B, int H, int W, int C, int r, int heads,
                        float* workspace, int64_t ws_bytes, hipStream_t stream);

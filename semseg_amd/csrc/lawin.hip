@@ -25,12 +25,7 @@ int lawin_attn_fwd_mfma(const void* theta, int64_t ldt, const void* pg, void* y,
 int lawin_attn_bwd_mfma(const void* theta, int64_t ldt, const void* pg, const void* y, int64_t ldy, const void* dy, int64_t lddy,
                         const float* lse, void* dtheta, int64_t lddt, void* dpg, int B, int H, int W, int inter, int heads, hipStream_t stream);
 
-struct WinGeom { int B, H, W, nh, nw, r, st, pad, gh, gw; };
-static inline WinGeom win_geom(int B, int H, int W, int r) {
-    WinGeom g; g.B = B; g.H = H; g.W = W; g.nh = H / 8; g.nw = W / 8; g.r = r; g.st = 8 / r; g.pad = 4 * (r - 1);
-    g.gh = (g.nh - 1) * g.st + 8; g.gw = (g.nw - 1) * g.st + 8;
-    return g;
-}
+#include "lawin_geom.h"
 
 // ------------------------------------------------------------------ pooled context grid
 template <typename T>
@@ -399,11 +394,17 @@ extern "C" int ss_lawin_gather_bwd(int dtype, const void* dctx, float* dG, int B
 }
 
 // Wm: [heads][64][64] fp32, bm: [heads][64] fp32.  Exactly one of G (pooled grid, gather) / xwin (window-ordered) is given.
+// workspace (optional): heads*64*64 bf16 for the packed weights of the matrix-core path (ss_lawin_mix_workspace bytes); without it,
+// in fp32, or for head widths it does not cover, the vector-ALU kernel runs.
+extern "C" int64_t ss_lawin_mix_workspace(int heads) { return lawin_mix_mfma_workspace(heads); }
 extern "C" int ss_lawin_mix(int dtype, const void* G, const void* xwin, const float* Wm, const float* bm, void* out, int B, int H, int W,
-                            int C, int r, int heads, int transpose, hipStream_t stream) {
+                            int C, int r, int heads, int transpose, void* workspace, int64_t ws_bytes, hipStream_t stream) {
     SS_CHECK((G != nullptr) != (xwin != nullptr) && Wm && out, "ss_lawin_mix: need exactly one of G / xwin, and Wm, out");
     if (check_geom(B, H, W, r, C, "ss_lawin_mix")) return -1;
     SS_CHECK(heads > 0 && C % heads == 0 && C / heads <= 256, "ss_lawin_mix: C/heads must be an integer <= 256");
+    if (dtype == SS_BF16 && workspace && ws_bytes >= lawin_mix_mfma_workspace(heads) && aligned16(workspace) &&
+        lawin_mix_mfma_ok(C, heads, G ? G : xwin, out))
+        return lawin_mix_mfma(G, xwin, Wm, bm, out, B, H, W, C, r, heads, transpose, workspace, stream);
     WinGeom g = win_geom(B, H, W, r);
     const int cg = C / heads, wpb = 256 / cg;
     const int64_t nwin = (int64_t)B * g.nh * g.nw;
@@ -415,10 +416,14 @@ extern "C" int ss_lawin_mix(int dtype, const void* G, const void* xwin, const fl
 }
 
 // dWb: [heads][64][65] fp32 (64 weight columns + bias).  workspace >= nchunks*heads*64*65 floats.
-extern "C" int64_t ss_lawin_mix_wgrad_workspace(int B, int H, int W, int heads) {
+extern "C" int64_t ss_lawin_mix_wgrad_workspace(int B, int H, int W, int C, int heads) {
     int64_t nwin = (int64_t)B * (H / 8) * (W / 8);
     int64_t chunks = cdiv(2048, heads); if (chunks > nwin) chunks = nwin; if (chunks < 1) chunks = 1;
     int64_t wpc = cdiv(nwin, chunks); chunks = cdiv(nwin, wpc);
+    if (heads > 0 && C % 128 == 0 && C % heads == 0) {                   // slabs of the matrix-core path
+        const int64_t m = lawin_mix_wgrad_mfma_slabs(B, H, W, C, heads);
+        if (m > chunks) chunks = m;
+    }
     return chunks * heads * 64 * 65 * 4;
 }
 extern "C" int ss_lawin_mix_wgrad(int dtype, const void* G, const void* dwin, float* dWb, int B, int H, int W, int C, int r, int heads,
@@ -428,6 +433,9 @@ extern "C" int ss_lawin_mix_wgrad(int dtype, const void* G, const void* dwin, fl
     SS_CHECK(heads > 0 && C % heads == 0 && C / heads <= 256, "ss_lawin_mix_wgrad: C/heads must be an integer <= 256");
     WinGeom g = win_geom(B, H, W, r);
     const int64_t nwin = (int64_t)B * g.nh * g.nw;
+    if (dtype == SS_BF16 && lawin_mix_mfma_ok(C, heads, G, dwin) &&
+        ws_bytes >= lawin_mix_wgrad_mfma_slabs(B, H, W, C, heads) * heads * 64 * 65 * 4)
+        return lawin_mix_wgrad_mfma(G, dwin, dWb, B, H, W, C, r, heads, workspace, stream);
     int64_t chunks = cdiv(2048, heads); if (chunks > nwin) chunks = nwin; if (chunks < 1) chunks = 1;
     const int64_t wpc = cdiv(nwin, chunks); chunks = cdiv(nwin, wpc);
     SS_CHECK(ws_bytes >= chunks * heads * 64 * 65 * 4, "ss_lawin_mix_wgrad: workspace too small");

@@ -500,7 +500,9 @@ def lawin_mix(Wm, bm, B, H, W, r, heads, G=None, xwin=None, transpose=False):
     _f32(Wm, 'Wm', heads * 4096)
     _f32(bm, 'bm', heads * 64)
     out = torch.empty((nwin * 64, C), dtype=src.dtype, device=dev)
-    check(lib().ss_lawin_mix(dt(src), _p(G), _p(xwin), _p(Wm), _p(bm), _p(out), B, H, W, C, r, heads, int(transpose), _stream()))
+    ws = workspace(dev, lib().ss_lawin_mix_workspace(heads))
+    check(lib().ss_lawin_mix(dt(src), _p(G), _p(xwin), _p(Wm), _p(bm), _p(out), B, H, W, C, r, heads, int(transpose), _p(ws), ws.numel(),
+                             _stream()))
     return out
 
 
@@ -512,7 +514,7 @@ def lawin_mix_wgrad(G, dwin, B, H, W, r, heads):
     if not G.is_contiguous() or not dwin.is_contiguous() or dwin.shape != (nwin * 64, C) or dwin.dtype != G.dtype:
         raise ValueError('lawin_mix_wgrad: bad tensors')
     out = torch.empty((heads, 64, 65), dtype=torch.float32, device=dev)
-    ws = workspace(dev, lib().ss_lawin_mix_wgrad_workspace(B, H, W, heads))
+    ws = workspace(dev, lib().ss_lawin_mix_wgrad_workspace(B, H, W, C, heads))
     check(lib().ss_lawin_mix_wgrad(dt(G), _p(G), _p(dwin), _p(out), B, H, W, C, r, heads, _p(ws), ws.numel(), _stream()))
     return out
 

@@ -323,3 +323,44 @@ def test_lawin_window_attention(ops, dtype, B, H, W, inter, heads):
     tw2 = wide[:, 8:8 + inter].float().cpu().view(B, nh, 8, nw, 8, heads, d).permute(0, 1, 3, 5, 2, 4, 6).reshape(nwin, heads, 64, d)
     ref2 = (torch.softmax(tw2 @ phi.detach().transpose(-1, -2) / math.sqrt(d), -1) @ g.detach()).view(B, nh, nw, heads, 8, 8, d)
     assert rel(y2, ref2.permute(0, 1, 4, 2, 5, 3, 6).reshape(B * H * W, inter)) < _tol(dtype)
+
+
+def _gather_windows(G, B, H, W, r):
+    """window-ordered [nwin*64, C] view of the pooled grid (the 8x8 cell block of every window), as the kernels gather it."""
+    nh, nw, st = H // 8, W // 8, 8 // r
+    gh, gw = (nh - 1) * st + 8, (nw - 1) * st + 8
+    Gi = G.reshape(B, gh, gw, -1)
+    rows = []
+    for b in range(B):
+        for i in range(nh):
+            for j in range(nw):
+                rows.append(Gi[b, i * st:i * st + 8, j * st:j * st + 8].reshape(64, -1))
+    return torch.cat(rows, 0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('C,heads,r', [(128, 16, 2), (128, 8, 4), (128, 4, 8), (256, 4, 2), (128, 1, 4), (64, 8, 2), (128, 64, 8)])
+def test_lawin_position_mixing(ops, dtype, C, heads, r):
+    """modules/lawin.py:44-46,62-69 -- out = x + W_h x + b_h over the 64 window positions, its transpose, and dW / db; head widths
+    8..128 with C % 128 == 0 take the matrix-core kernels in bf16, everything else the vector-ALU ones."""
+    B, H, W = 2, 16, 24
+    nwin = B * (H // 8) * (W // 8)
+    st = 8 // r
+    gh, gw = (H // 8 - 1) * st + 8, (W // 8 - 1) * st + 8
+    G = rnd(B * gh * gw, C)
+    Wm, bm = rnd(heads, 64, 64, seed=1) / 8, 0.1 * rnd(heads, 64, seed=2)
+    d = rnd(nwin * 64, C, seed=3)
+    cg = C // heads
+    xw = _gather_windows(q(G, dtype), B, H, W, r).reshape(nwin, 64, heads, cg)
+    ref = xw + torch.einsum('hqp,wphc->wqhc', Wm, xw) + bm.t().reshape(1, 64, heads, 1)
+    out = ops.lawin_mix(dev(Wm), dev(bm), B, H, W, r, heads, G=dev(G, dtype))
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-4
+    assert rel(out, ref.reshape(nwin * 64, C)) < tol
+    dq = q(d, dtype).reshape(nwin, 64, heads, cg)
+    refT = dq + torch.einsum('hpq,wphc->wqhc', Wm, dq)
+    outT = ops.lawin_mix(dev(Wm), None, B, H, W, r, heads, xwin=dev(d, dtype), transpose=True)
+    assert rel(outT, refT.reshape(nwin * 64, C)) < tol
+    dWb = ops.lawin_mix_wgrad(dev(G, dtype), dev(d, dtype), B, H, W, r, heads)
+    refW = torch.einsum('wqhc,wphc->hqp', dq, xw)
+    assert rel(dWb[:, :, :64], refW) < tol
+    assert rel(dWb[:, :, 64], dq.sum((0, 3)).t()) < tol
