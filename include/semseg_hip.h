@@ -231,6 +231,26 @@ int ss_inject_fuse(int dtype, const void* local, int64_t ldl, const void* gact, 
 int ss_bilinear_add(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
                     hipStream_t stream);
 
+/* ---- TopFormer RefinerHead, inference (modules/heads.py:22-39 SimpleAttention, :42-60 AttentionUniRes, :173-269 RefinerHead;
+ * core/models.py:52-72,99-115).  Token matrices [images * rows_per_image, C], all reductions in a fixed order.
+ * ss_image_moments: moments[img][0][c] = mean over the image's rows of f(x[:, c]), [img][1][c] = sum (f(x) - mean)^2;
+ *   pre_act 0: f = identity (SimAM, :29-34), 5: f = sigmoid (the 'CAN' group conv's activation feeding GroupNorm, :200-222).
+ *   workspace: images * 1024 * 2 * C floats.
+ * ss_simam_apply: y = x * sigmoid((x - mean)^2 / (4 (k + M2 / (rows_per_image - 1))) + 0.5), k = uni_res.attention.k (:27-39).
+ * ss_refiner_fold: nn.GroupNorm(groups, groups*cg) statistics per image from the per-column moments (columns g*pitch + j, j < cg,
+ *   hold channel g*cg + j; biased variance), its affine, and the fixed linear map L [lrows][groups*cg] that follows it (the
+ *   view + Conv3d(n_heads -> 1) of :262-267, or the classifier after the bilinear resize, core/models.py:103-115) folded into
+ *   M [images][mrows][ncol] and cvec [images][mrows] (moments are [images][2][ncol]; rows >= lrows and padding columns zero).
+ * ss_image_affine: out[p][r] = sum_c M[img][r][c] f(in[p][c]) + cvec[img][r]; in fp32 [P, cin], out of out_dtype [P, mrows]. */
+int ss_image_moments(int dtype, const void* x, int64_t ld, int64_t rows_per_image, int C, int images, int pre_act, float* moments,
+                     float* workspace, int64_t ws_bytes, hipStream_t stream);
+int ss_simam_apply(int dtype, const void* x, int64_t ldx, const float* moments, const float* k, void* y, int64_t ldy,
+                   int64_t rows_per_image, int C, int images, hipStream_t stream);
+int ss_refiner_fold(const float* moments, int64_t rows_per_image, int images, int groups, int cg, int pitch, int ncol, float eps, const float* gamma,
+                    const float* beta, const float* L, int lrows, int mrows, float* M, float* cvec, hipStream_t stream);
+int ss_image_affine(int out_dtype, const float* in, int64_t ldi, const float* M, const float* cvec, void* out, int64_t ldo,
+                    int64_t rows_per_image, int images, int cin, int mrows, int pre_act, hipStream_t stream);
+
 /* ---- optimizer step right after the gradient all-reduce: AdaBound as configured in train.py:53-58
  * (torch_optimizer.AdaBound, absent here: restated from Luo et al. 2019, parity unpinned) over FLAT fp32 buffers -- one launch
  * for the whole model.  step_size / lower / upper are the per-step scalars of the published algorithm (host computed);

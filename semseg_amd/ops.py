@@ -816,3 +816,63 @@ def bilinear_add(x, y, B, hi, wi, ho, wo):
         raise ValueError('bilinear_add: bad shapes')
     check(lib().ss_bilinear_add(dt(x), _p(x), ldx, _p(y), ldy, B, hi, wi, ho, wo, C, _stream()))
     return y
+
+
+# ---------------------------------------------------------------------------------- TopFormer RefinerHead (inference)
+SIGMOID = 5
+
+
+def image_moments(x, images, pre_act=0):
+    """x [images*n, C] -> moments [images, 2, C] fp32: per-image mean of f(x) and sum (f(x) - mean)^2 (f = sigmoid if pre_act == 5)."""
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    if images <= 0 or rows % images:
+        raise ValueError('image_moments: rows not divisible by images')
+    out = torch.empty((images, 2, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, images * COLRED_BLOCKS * 2 * C * 4)
+    check(lib().ss_image_moments(dt(x), _p(x), ld, rows // images, C, images, pre_act, _p(out), _p(ws), ws.numel(), _stream()))
+    return out
+
+
+def simam_apply(x, moments, k, images, out=None):
+    dev = _dev(x)
+    rows, C, ldx = _mat(x, 'x')
+    _f32(moments, 'moments', images * 2 * C), _f32(k, 'k', 1)
+    if rows % images:
+        raise ValueError('simam_apply: rows not divisible by images')
+    if out is None:
+        out = torch.empty((rows, C), dtype=x.dtype, device=dev)
+    ro, Co, ldy = _mat(out, 'out')
+    if (ro, Co) != (rows, C) or out.dtype != x.dtype:
+        raise ValueError('simam_apply: bad out')
+    check(lib().ss_simam_apply(dt(x), _p(x), ldx, _p(moments), _p(k), _p(out), ldy, rows // images, C, images, _stream()))
+    return out
+
+
+def refiner_fold(moments, rows_per_image, groups, cg, pitch, eps, gamma, beta, L, mrows):
+    """GroupNorm(groups, groups*cg) on columns g*pitch + j of an [.., ncol] map, then the fixed map L [lrows, groups*cg]
+    ->  (M [images, mrows, ncol], c [images, mrows])."""
+    dev = _dev(moments)
+    images, two, ncol = moments.shape
+    _f32(moments, 'moments'), _f32(gamma, 'gamma', groups * cg), _f32(beta, 'beta', groups * cg)
+    lrows = L.shape[0]
+    _f32(L, 'L', lrows * groups * cg)
+    M = torch.empty((images, mrows, ncol), dtype=torch.float32, device=dev)
+    c = torch.empty((images, mrows), dtype=torch.float32, device=dev)
+    check(lib().ss_refiner_fold(_p(moments), rows_per_image, images, groups, cg, pitch, ncol, eps, _p(gamma), _p(beta), _p(L), lrows, mrows, _p(M),
+                                _p(c), _stream()))
+    return M, c
+
+
+def image_affine(x, M, c, out_dtype=torch.float32, pre_act=0):
+    """x fp32 [images*n, cin] -> out [images*n, mrows] = M[img] f(x) + c[img]."""
+    dev = _dev(x)
+    rows, cin, ldi = _mat(x, 'x')
+    images, mrows, cin2 = M.shape
+    if x.dtype != torch.float32 or cin2 != cin or rows % images:
+        raise ValueError('image_affine: bad shapes')
+    _f32(M, 'M'), _f32(c, 'c', images * mrows)
+    out = torch.empty((rows, mrows), dtype=out_dtype, device=dev)
+    code = {torch.float32: 0, torch.bfloat16: 1}[out_dtype]
+    check(lib().ss_image_affine(code, _p(x), ldi, _p(M), _p(c), _p(out), mrows, rows // images, images, cin, mrows, pre_act, _stream()))
+    return out

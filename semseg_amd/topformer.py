@@ -210,7 +210,7 @@ class _Plan:
         self.inj = OrderedDict()
         for name, m in net.post_stages.named_children():
             self.inj[name] = {k: (lambda wb: (_w2(wb[0], T), wb[1]))(getattr(m, k).folded()) for k in ('local_embedding', 'global_embedding', 'global_act')}
-        if model.head is not None:
+        if isinstance(model.head, SimpleHead):
             w, b = model.head.conv.folded()
             self.head = (_w2(w, T), b)
             wc = model.classifier.net.p_conv.conv.weight.detach().float().reshape(model.out_channels, -1)
@@ -218,6 +218,28 @@ class _Plan:
             wcp = torch.zeros((ncp, wc.shape[1]), device=wc.device)
             wcp[:model.out_channels] = wc
             self.cls = _w2(wcp, T)
+        elif isinstance(model.head, RefinerHead):
+            hd = model.head
+            nc, d = hd.embedding_dim, hd.n_heads
+            ncp = (nc + 7) // 8 * 8
+            wg = hd.group_conv.net.p_conv.conv.weight.detach().float().reshape(d, nc, -1)          # group g: out channels g*nc..g*nc+nc-1
+            wgp = torch.zeros((d, ncp, wg.shape[2]), device=wg.device)
+            wgp[:, :nc] = wg
+            self.group_w = [_w2(wgp[g], T) for g in range(d)]
+            gn1, gn2 = hd.group_conv.net.norm, hd.norm
+            self.gn1 = (gn1.weight.detach().float().contiguous(), gn1.bias.detach().float().contiguous(), float(gn1.eps))
+            # view(n, nc, d, h, w) + Conv3d(d -> 1): r[c] = sum_dd w3[dd] t[c*d + dd]  (modules/heads.py:262-267)
+            w3 = hd.reduce_conv.net.p_conv.conv.weight.detach().float().reshape(d)
+            L1 = torch.zeros((nc, nc * d), device=w3.device)
+            for c in range(nc):
+                L1[c, c * d:(c + 1) * d] = w3
+            self.L1 = L1.contiguous()
+            if isinstance(gn2, nn.GroupNorm):
+                self.gn2 = (gn2.weight.detach().float().contiguous(), gn2.bias.detach().float().contiguous(), float(gn2.eps), gn2.num_groups)
+            else:
+                self.gn2 = None
+            self.L2 = model.classifier.net.p_conv.conv.weight.detach().float().reshape(model.out_channels, nc).contiguous()
+            self.k = hd.uni_res.attention.k.detach().float().reshape(1).contiguous()
 
 
 class TopFormerBackBone(nn.Module):
@@ -313,20 +335,75 @@ class SimpleHead(nn.Module):
         self.conv = ConvUnit(in_channels, embedding_dim, act=RELU6)
 
 
+class _ConvND(nn.Module):
+    """net.p_conv.conv (+ net.norm = GroupNorm) with the naming of modules/blocks.py ConvolutionBlock, for the RefinerHead's convolutions."""
+
+    def __init__(self, conv, norm=None):
+        super().__init__()
+        p_conv = nn.Sequential()
+        p_conv.add_module('conv', conv)
+        self.net = nn.Sequential()
+        self.net.add_module('p_conv', p_conv)
+        if norm is not None:
+            self.net.add_module('norm', norm)
+
+
+class RefinerHead(nn.Module):
+    """modules/heads.py:173-269: parameter container.  SimAM per stage -> bilinear to the finest map -> concat -> grouped 1x1
+    conv (group g = stage g) -> sigmoid -> GroupNorm(n_heads) -> view(n, c, d, h, w) + Conv3d(d -> 1) -> GroupNorm(c groups)."""
+
+    def __init__(self, n_heads, in_channels, embedding_dim, resize_mode='bilinear', attention_factor=1e-2,
+                 norm_cfg=frozenset({'alias': 'groupnorm', 'affine': True}.items()), act_cfg=frozenset({'alias': 'sigmoid'}.items())):
+        super().__init__()
+        norm_cfg = dict(norm_cfg) if norm_cfg is not None else None
+        act_cfg = dict(act_cfg) if act_cfg is not None else None
+        if resize_mode != 'bilinear' or act_cfg != {'alias': 'sigmoid'}:
+            raise NotImplementedError('RefinerHead on the MI355X path: bilinear resize and sigmoid activation (the reference defaults) only')
+        if norm_cfg and (norm_cfg.get('alias') != 'groupnorm' or not norm_cfg.get('affine', True)):
+            raise NotImplementedError("RefinerHead on the MI355X path: norm_cfg must be affine 'groupnorm' (the reference default) or empty")
+        self.n_heads, self.embedding_dim = n_heads, embedding_dim
+        self.uni_res = _container(attention=_container())
+        self.uni_res.attention.k = nn.Parameter(torch.tensor(attention_factor))
+        self.group_conv = _ConvND(nn.Conv2d(n_heads * in_channels, n_heads * embedding_dim, 1, groups=n_heads, bias=False),
+                                  nn.GroupNorm(n_heads, n_heads * embedding_dim))
+        self.reduce_conv = _ConvND(nn.Conv3d(n_heads, 1, 1, bias=False))
+        self.norm = nn.GroupNorm(norm_cfg.get('num_groups', embedding_dim), embedding_dim, **({'eps': norm_cfg['eps']} if 'eps' in norm_cfg else {})) \
+            if norm_cfg else nn.Identity()
+
+
 class TopFormerModel(nn.Module):
     def __init__(self, num_classes: int, config_alias: str = 'B', input_channels: int = 3, injection_type: str = 'dot_sum',
                  fusion: str = 'sum', head_cfg=frozenset({'alias': 'simple'}.items())):
         super().__init__()
         assert isinstance(fusion, str) and fusion.lower() in {'concat', 'sum'}, f"Unknown fusion: {fusion}\nSupported fusion modes are: {{'concat', 'sum'}}"
         head_cfg = dict(head_cfg)
-        if head_cfg.get('alias') != 'simple' or fusion.lower() != 'sum':
-            raise NotImplementedError("TopFormerModel on the MI355X path implements head 'simple' with fusion 'sum' this round "
-                                      "(RefinerHead / concat fusion: next)")
+        alias = head_cfg.pop('alias', None)
+        self.fusion = fusion.lower()
         self.out_channels = num_classes
         self.backbone = TopFormerBackBone(config_alias, input_channels, injection_type)
-        inc = tuple(c['outc'] for c in self.backbone.injection_configs.values())[0]
-        self.head = SimpleHead(inc, inc)
-        self.classifier = ConvUnit(inc, num_classes, norm=False)
+        chans = tuple(c['outc'] for c in self.backbone.injection_configs.values())
+        if len(set(chans)) != 1:
+            raise NotImplementedError('TopFormerModel: the injected stages must share one channel count (all reference configs do)')
+        inc = chans[0] if self.fusion == 'sum' else sum(chans)
+        if alias == 'refiner':
+            if self.fusion != 'sum':
+                # core/models.py:46-56 hands the head in_channels = sum of the stage widths, so its grouped conv expects n_heads times the
+                # channels the concat actually has and the reference raises at the first forward; refuse at construction instead
+                raise ValueError("TopFormerModel: head 'refiner' needs fusion='sum' (with 'concat' the reference's group conv cannot run)")
+            self.head = RefinerHead(len(self.backbone.net.stage_names), inc, num_classes, **head_cfg)
+            self.classifier = ConvUnit(num_classes, num_classes, norm=False)
+        elif alias == 'simple':
+            # core/models.py:46-49,73-76 sizes the head for the model-level `fusion` but the head fuses by its OWN cfg entry (default
+            # 'sum'); when the two differ the reference's conv raises a channel mismatch at the first forward: refuse at construction
+            head_fusion = str(head_cfg.pop('fusion', 'sum')).lower()
+            if head_cfg.pop('resize_mode', 'bilinear') != 'bilinear' or head_cfg:
+                raise NotImplementedError(f'SimpleHead on the MI355X path takes the reference defaults only (got {sorted(head_cfg)})')
+            if head_fusion != self.fusion:
+                raise ValueError(f"TopFormerModel: fusion={self.fusion!r} but head_cfg fusion={head_fusion!r}: the head conv would not match its input")
+            self.head = SimpleHead(inc, inc)
+            self.classifier = ConvUnit(inc, num_classes, norm=False)
+        else:
+            raise NotImplementedError(f'Specified head ({alias}) is unknown or not compatible!')
 
     def train(self, mode: bool = True):
         self.backbone._plans = {}
@@ -341,10 +418,47 @@ class TopFormerModel(nn.Module):
         with torch.no_grad():
             plan = self.backbone._plan_for(self, x)
             feats = list(self.backbone._run(x, plan).values())
-            acc, h4, w4 = feats[0]
-            for t, h, w in feats[1:]:
-                ops.bilinear_add(t, acc, b, h, w, h4, w4)
-            y = ops.gemm_nt(acc, plan.head[0], bias=plan.head[1], act=RELU6)
-            logits4 = ops.gemm_nt(y, plan.cls)                                  # [B*h4*w4, round8(nc)], classifier before the up-sampling
+            h4, w4 = max(f[1] for f in feats), max(f[2] for f in feats)         # UniRes target: the largest map (modules/heads.py:78-82)
+            if isinstance(self.head, RefinerHead):
+                logits4 = self._refiner(plan, feats, b, h4, w4)
+            else:
+                if self.fusion == 'sum':
+                    if (feats[0][1], feats[0][2]) != (h4, w4):
+                        raise ValueError('TopFormerModel: the first stage must be the finest map')
+                    acc = feats[0][0]
+                    for t, h, w in feats[1:]:
+                        ops.bilinear_add(t, acc, b, h, w, h4, w4)
+                else:                                                           # Concat(dim=1): stage g fills channel slice g
+                    C = feats[0][0].shape[1]
+                    acc = torch.empty((b * h4 * w4, C * len(feats)), dtype=plan.T, device=x.device)
+                    for g, (t, h, w) in enumerate(feats):
+                        ops.bilinear_fwd(t, b, h, w, h4, w4, out=acc[:, g * C:(g + 1) * C])
+                y = ops.gemm_nt(acc, plan.head[0], bias=plan.head[1], act=RELU6)
+                logits4 = ops.gemm_nt(y, plan.cls)                              # [B*h4*w4, round8(nc)], classifier before the up-sampling
             full = ops.bilinear_fwd(logits4, b, h4, w4, H, W)
         return full.view(b, H, W, -1)[..., :self.out_channels].permute(0, 3, 1, 2)
+
+    def _refiner(self, plan, feats, b, h4, w4):
+        """RefinerHead.forward (modules/heads.py:255-269) + the classifier (core/models.py:103-115) -> logits at the finest stage's size.
+        The grouped 1x1 conv runs per stage BEFORE the bilinear resize (both linear, and the resize weights sum to one), and the
+        classifier before the final resize; GroupNorm + the linear map after it become one small matrix per image."""
+        hd = self.head
+        nc, d = hd.embedding_dim, hd.n_heads
+        ncp = (nc + 7) // 8 * 8
+        n4 = h4 * w4
+        u = torch.empty((b * n4, d * ncp), dtype=torch.float32, device=feats[0][0].device)
+        for g, (t, h, w) in enumerate(feats):
+            att = ops.simam_apply(t, ops.image_moments(t, b), plan.k, b)
+            dst = u[:, g * ncp:(g + 1) * ncp]
+            if (h, w) == (h4, w4):
+                ops.gemm_nt(att, plan.group_w[g], out=dst, out_f32=True)
+            else:
+                ops.bilinear_fwd(ops.gemm_nt(att, plan.group_w[g], out_f32=True), b, h, w, h4, w4, out=dst)
+        m1, c1 = ops.refiner_fold(ops.image_moments(u, b, pre_act=ops.SIGMOID), n4, d, nc, ncp, plan.gn1[2], plan.gn1[0], plan.gn1[1], plan.L1, ncp)
+        r = ops.image_affine(u, m1, c1, pre_act=ops.SIGMOID)                   # [b*n4, ncp] fp32, padding columns zero
+        if plan.gn2 is not None:
+            gamma, beta, eps, groups = plan.gn2
+            m2, c2 = ops.refiner_fold(ops.image_moments(r, b), n4, groups, nc // groups, nc // groups, eps, gamma, beta, plan.L2, ncp)
+        else:
+            raise NotImplementedError('RefinerHead without its final norm is not built on the MI355X path')
+        return ops.image_affine(r, m2, c2, out_dtype=plan.T)

@@ -1,7 +1,9 @@
 """Golden vectors / manifests for TopFormerModel from the REFERENCE (imported from /root/reference, CPU fp32, eval mode).
 The reference's TopFormer can be constructed once per process, so this script builds ONE model per run:
 
-    cd /root/repo && for a in B:simple B:refiner S:simple T:simple; do PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_topformer_golden.py $a; done
+    cd /root/repo && for a in B:simple B:refiner S:simple T:simple T:simple:concat; do PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_topformer_golden.py $a; done
+
+(alias:head[:fusion]; fusion defaults to 'sum' and is part of the file name only when given.)
 """
 import json
 import os
@@ -18,7 +20,11 @@ from semseg_amd.detinit import det_fill_, det_input  # noqa: E402
 from core.models import TopFormerModel  # noqa: E402  (reference)
 from modules.topformer import TopFormerBackBone  # noqa: E402  (reference)
 
-alias, head = sys.argv[1].split(':')
+alias, head, *rest = sys.argv[1].split(':')
+fusion = rest[0] if rest else 'sum'
+tag = f'{alias}_{head}' + (f'_{fusion}' if rest else '')
+# core/models.py:46-49 sizes the head for the model-level fusion but does not forward it: the head needs the same mode in its own cfg
+head_cfg = {'alias': head, **({'fusion': fusion} if rest else {})}
 cfgs = getattr(TopFormerBackBone, '_TopFormerBackBone__available_configs')
 tables = {}
 for a, c in cfgs.items():
@@ -28,9 +34,9 @@ for a, c in cfgs.items():
                  'depths': c['depths'], 'key_dim': c['key_dim'], 'attn_ratios': c['attn_ratios'], 'mlp_ratios': c['mlp_ratios']}
 json.dump(tables, open(os.path.join(HERE, 'topformer_configs.json'), 'w'), indent=1)
 
-net = det_fill_(TopFormerModel(6, alias, 3, 'dot_sum', 'sum', frozenset({'alias': head}.items()))).eval()
+net = det_fill_(TopFormerModel(6, alias, 3, 'dot_sum', fusion, frozenset(head_cfg.items()))).eval()
 manifest = {k: list(v.shape) for k, v in net.state_dict().items()}
-json.dump(manifest, open(os.path.join(HERE, f'topformer_{alias}_{head}_manifest.json'), 'w'), indent=0)
+json.dump(manifest, open(os.path.join(HERE, f'topformer_{tag}_manifest.json'), 'w'), indent=0)
 x = det_input('top.x', (2, 3, 128, 192))
 with torch.no_grad():
     feats = net.backbone(x)
@@ -39,5 +45,5 @@ save = {'logits': out.numpy()}
 for k, v in feats.items():                      # the two coarsest injected maps (the fine ones would be megabytes)
     if k in ('stage_3', 'stage_4'):
         save['feat.' + k] = v.numpy()
-np.savez_compressed(os.path.join(HERE, f'topformer_{alias}_{head}.npz'), **save)
-print(alias, head, 'logits', tuple(out.shape), 'params', sum(p.numel() for p in net.parameters()), 'keys', len(manifest))
+np.savez_compressed(os.path.join(HERE, f'topformer_{tag}.npz'), **save)
+print(tag, 'logits', tuple(out.shape), 'params', sum(p.numel() for p in net.parameters()), 'keys', len(manifest))
