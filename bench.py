@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--workload', default='mit_lawin', choices=['mit_lawin', 'dnet', 'topformer'],
                     help="mit_lawin = BASELINE configs[1] (the headline); dnet = configs[2] per-GPU step (DNet-T, embed 256, batch 8, Dice loss)")
     ap.add_argument('--variant', default='B2')
+    ap.add_argument('--head', default='simple', choices=['simple', 'refiner'], help='TopFormer head (configs[3]; predict.py uses refiner)')
     ap.add_argument('--embed', type=int, default=512)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--size', type=int, default=1024)
@@ -240,7 +241,7 @@ def cpu_baseline():
 
 
 def topformer_inference(a, world, rank, dev):
-    """configs[3]: TopFormer-B (SimpleHead) inference images/sec on 2048x2048 tiles, replicas only (no collective on the data path)."""
+    """configs[3]: TopFormer-B (SimpleHead or RefinerHead) inference images/sec on 2048x2048 tiles, replicas only (no collective on the data path)."""
     from semseg_amd.topformer import TopFormerModel
     from semseg_amd.detinit import det_fill_
     from semseg_amd.runtime import set_compute_dtype
@@ -248,7 +249,7 @@ def topformer_inference(a, world, rank, dev):
     set_compute_dtype(torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
     size = a.size if a.size != 1024 else 2048
     batch = a.batch if a.batch != 16 else 4
-    net = det_fill_(TopFormerModel(6, 'B')).to(dev).eval()
+    net = det_fill_(TopFormerModel(6, 'B', head_cfg=frozenset({'alias': a.head}.items()))).to(dev).eval()
     x, _ = synthetic_batch(batch, size, rank, dev)
 
     def fence():
@@ -275,7 +276,7 @@ def topformer_inference(a, world, rank, dev):
         res = {'metric': 'inference images/sec @2048x2048 (TopFormer-B)', 'value': batch * world * a.steps / dt, 'unit': 'images/s', 'n_gpus': world,
                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-               'config': {'workload': f'configs[3]: TopFormer-B + SimpleHead inference, {size}x{size}', 'per_gpu_batch': batch,
+               'config': {'workload': f'configs[3]: TopFormer-B + {a.head} head inference, {size}x{size}', 'per_gpu_batch': batch,
                           'global_batch': batch * world, 'parallelism': f'replicas x{world}'},
                'roofline': roofline_from_table(table)}
         if a.table:
