@@ -278,7 +278,15 @@ extern "C" int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, co
     return ss_fail(-1, "ss_gemm_nt: unsupported dtype %d", dtype);
 }
 
-static void tn_plan(int64_t M, int64_t N, int64_t R, int bk, int* nsplit, int64_t* rps) {
+static int tn_big_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SS_GEMM_TN_BIG"); on = !(e && e[0] == '0'); }
+    return on;
+}
+
+// returns true when the split was planned for the 256-tile bf16 kernel (gemm_bf16_tn_big.hip)
+static bool tn_plan(int64_t M, int64_t N, int64_t R, int bk, int* nsplit, int64_t* rps) {
+    if (bk == 64 && tn_big_enabled() && ss_big_tn_plan(M, N, R, nsplit, rps)) return true;
     // split the reduction rows so that ~8 workgroups per CU exist (tail quantisation), every split has >= 4 k-tiles, and the fp32 slabs
     // (written once, read once) stay below ~a quarter of the operand bytes
     int64_t tiles = cdiv(M, 128) * cdiv(N, N <= 64 ? 64 : 128);
@@ -293,6 +301,7 @@ static void tn_plan(int64_t M, int64_t N, int64_t R, int bk, int* nsplit, int64_
     int64_t per = cdiv(cdiv(R, s), bk) * bk;
     *rps = per;
     *nsplit = (int)cdiv(R, per);
+    return false;
 }
 
 extern "C" int ss_colsum(int dtype, const void* x, int64_t ld, int64_t rows, int C, int groups, float scale, float* out,
@@ -329,7 +338,7 @@ static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, in
     SS_CHECK(lda >= M && ldb >= N && ldc >= N, "ss_gemm_tn: leading dimension smaller than the row");
     int ns; int64_t rps;
     int bk = dtype == SS_BF16 ? 64 : 32;
-    tn_plan(M, N, R, bk, &ns, &rps);
+    const bool big = tn_plan(M, N, R, bk, &ns, &rps);
     const int64_t ws_need = ((int64_t)ns * M * N + kColsumWsRows * M) * 4;
     SS_CHECK(ws_bytes >= ws_need, "ss_gemm_tn: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)ws_need);
     float* cs_ws = (float*)workspace + (int64_t)ns * M * N;
@@ -352,7 +361,7 @@ static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, in
         f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = workspace; f.M = M; f.N = (int)N; f.K = R; f.lda = lda; f.ldb = ldb; f.ldc = N;
         f.k_per_split = rps;
         if (colsum && ns <= kColsumWsRows) { f.colsum_ws = cs_ws; cs_fused = true; }
-        int rc = ss_fast_tn_launch(f, ns, stream);
+        int rc = big && ss_big_tn_ok(f, ns) ? ss_big_tn_launch(f, ns, stream) : ss_fast_tn_launch(f, ns, stream);
         if (rc) return rc;
     } else if (N <= 64) {
         dim3 grid((unsigned)(cdiv(N, 64) * cdiv(M, 128)), 1, ns);

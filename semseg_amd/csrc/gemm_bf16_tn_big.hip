@@ -1,0 +1,170 @@
+// 256 x 256 x 64 tiles of the bf16 weight-gradient GEMM  slab[z][M,N] = sum_{r in split z} A[r,M]^T . B[r,N]  for the shapes
+// whose output is at least a tile wide both ways (the 128-tile kernel of gemm_bf16.hip moves 64 flop per byte from L2 into LDS
+// and stops where that path does; this tile halves the bytes per flop, as gemm_bf16_big.hip does for the NT product).
+//
+//   512 threads = 8 waves as 4 (m) x 2 (n), each wave a 64 x 128 block of the tile, one workgroup per CU, two stages of 64 KiB.
+//   Memory delivers both operands k-major ([r][m] and [r][n] rows), which is how they stay in LDS: a stage holds 64 rows of
+//   512 bytes per operand, filled global -> LDS without passing registers (global_load_lds_dwordx4: one wave instruction = 1 KiB
+//   = two rows).  MFMA fragments (k-contiguous per lane) come out through ds_read_b64_tr_b16.  With an unpadded 512-byte pitch
+//   the four rows of a transpose block would share their banks, so 16-byte slot s of row r lives at slot s ^ ((r & 3) << 2):
+//   the XOR is applied to the SOURCE address of the fill (an LDS-DMA destination is lane-linear) and to the fragment reads.
+//   Columns past M / N are filled from the tile's first column: they only reach accumulators that are never stored.
+//   Splits are whole k-tiles (R % 64 == 0 is part of the eligibility test), so no row needs masking.
+#include "common.h"
+#include "gemm_fast.h"
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ int xcd_remap_tnb(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(FastGemm p) {
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int PITCH = BM * 2;                      // 512-byte rows
+    constexpr int IMG = BK * PITCH;                    // one operand image: 32 KiB
+    constexpr int STAGE = 2 * IMG;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    // all output tiles of a run of consecutive splits on one XCD: they stream the same A / B rows through that XCD's L2
+    const int vid = xcd_remap_tnb(blockIdx.x, gridDim.x);
+    const int split = vid / p.ntiles, wg = vid % p.ntiles;
+    const int m0 = (wg / p.ntn) * BM, n0 = (wg % p.ntn) * BN;
+    const int64_t kbeg = (int64_t)split * p.k_per_split;
+    const int64_t kend = kbeg + p.k_per_split < p.K ? kbeg + p.k_per_split : p.K;
+    const int nk = (int)((kend - kbeg) / BK);
+
+    // LDS-DMA sources: piece q = wave*4 + i covers rows 2q, 2q+1 of a stage image; this lane fills physical slot (lane & 31) of
+    // row 2q + (lane >> 5), which holds logical slot (lane & 31) ^ ((row & 3) << 2)
+    const bf16* pa[4]; const bf16* pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 2 + (lane >> 5);
+        const int ls = (lane & 31) ^ ((row & 3) << 2);
+        const int ca = m0 + ls * 8 < p.M ? m0 + ls * 8 : m0;
+        const int cb = n0 + ls * 8 < p.N ? n0 + ls * 8 : n0;
+        pa[i] = p.A + (kbeg + row) * p.lda + ca;
+        pb[i] = p.B + (kbeg + row) * p.ldb + cb;
+    }
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 1) * STAGE + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void*)(pa[i] + (int64_t)kt * BK * p.lda), (lds_void*)(st + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void*)(pb[i] + (int64_t)kt * BK * p.ldb), (lds_void*)(st + IMG + i * 1024), 16, 0, 0);
+    };
+
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // transpose-read addressing (see gemm_bf16.hip): lane 4q+pp of a 16-lane group supplies row q, columns 4pp..4pp+3 of a
+    // 4 x 16 block and receives column (lane & 15).  Row = 16 ks + 8 lh + q (+4 for the upper half of the fragment).
+    const int l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3, gsel = (lane >> 4) & 1;
+    const int row_off = (8 * lh + tq) * PITCH;
+    const int sub_off = (gsel * 2 + (tp >> 1)) * 16 + (tp & 1) * 8;          // inside an aligned group of four slots
+    auto trfrag = [&](const char* img, int ks, int colbase) {                  // colbase: multiple of 32
+        const char* a0 = img + ks * 16 * PITCH + row_off + ((((colbase >> 3) ^ (tq << 2))) << 4) + sub_off;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 4 * PITCH));
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+        return f;
+    };
+
+    const bool do_cs = p.colsum_ws && n0 == 0;
+    float cs = 0.f;
+    if (nk > 0) issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // tile kt has landed; nobody still reads the other stage
+        if (kt + 1 < nk) issue(kt + 1);
+        const char* As = smem + (kt & 1) * STAGE;
+        const char* Bs = As + IMG;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 fa[2], fb[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[a] = trfrag(As, ks, wm * 64 + a * 32);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[b] = trfrag(Bs, ks, wn * 128 + b * 32);
+            if (do_cs) {                               // column sums of A (the bias gradient): wave (wm, wn) sums its a = wn fragment
+                const bf16x8 f = wn ? fa[1] : fa[0];
+                const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf16x2 pr = {f[2 * e], f[2 * e + 1]};
+                    cs = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, cs, false);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    if (do_cs) {                                       // lane = column (lane & 31) of the A fragment, k split over the lane halves
+        const float t = cs + __shfl_xor(cs, 32);
+        const int m = m0 + wm * 64 + wn * 32 + li;
+        if (lh == 0 && m < p.M) p.colsum_ws[(int64_t)split * p.M + m] = t;
+    }
+    // fp32 slab: lanes run along n (128-byte segments per register row)
+    float* C = (float*)p.C + (int64_t)split * p.M * p.N;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int col = n0 + wn * 128 + b * 32 + li;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < p.M) C[(int64_t)row * p.N + col] = acc[a][b][r];
+            }
+        }
+}
+
+// Plan for the 256-tile kernel: whole-chip launches of one workgroup per CU (tiles x splits <= 256, or several full rounds when the
+// output alone has more tiles), splits of whole k-tiles.  False when the shape does not suit the tile.
+bool ss_big_tn_plan(int64_t M, int64_t N, int64_t R, int* nsplit, int64_t* rps) {
+    if (M < 256 || N < 256 || M % 8 || N % 8 || R % 64 || R < 4096) return false;
+    const int64_t tm = cdiv(M, 256), tn = cdiv(N, 256), tiles = tm * tn;
+    if ((double)(tm * 256) * (double)(tn * 256) > 1.5 * (double)M * (double)N) return false;     // too much of the tiles would be padding
+    int64_t s = tiles >= 256 ? 1 : 256 / tiles;
+    const int64_t maxs = R / (8 * 64);                 // >= 8 k-tiles per split
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    const int64_t per = cdiv(cdiv(R, s), 64) * 64;
+    *rps = per;
+    *nsplit = (int)cdiv(R, per);
+    return true;
+}
+
+bool ss_big_tn_ok(const FastGemm& p, int nsplit) {
+    if (!aligned16(p.A) || !aligned16(p.B) || p.lda % 8 || p.ldb % 8 || p.M % 8 || p.N % 8) return false;
+    if (p.M < 256 || p.N < 256 || p.K % 64 || p.k_per_split % 64) return false;
+    return cdiv(p.M, 256) * cdiv(p.N, 256) * nsplit < (1LL << 30);
+}
+
+int ss_big_tn_launch(FastGemm p, int nsplit, hipStream_t st) {
+    p.ntn = (int)cdiv(p.N, 256);
+    p.ntiles = (int)(p.ntn * cdiv(p.M, 256));
+    hipLaunchKernelGGL(gemm_tn_bf16_256_kernel, dim3((unsigned)(p.ntiles * nsplit)), dim3(512), 0, st, p);
+    SS_LAUNCH_CHECK();
+    return 0;
+}

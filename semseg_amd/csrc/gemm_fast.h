@@ -24,6 +24,9 @@ bool ss_skinny_tn_ok(const void* B, int64_t ldb, int64_t M, int64_t N);
 int ss_skinny_tn_launch(const FastGemm& p, int nsplit, hipStream_t st);
 bool ss_big_nt_ok(const FastGemm& p);
 int ss_big_nt_launch(FastGemm p, hipStream_t st);
+bool ss_big_tn_plan(int64_t M, int64_t N, int64_t R, int* nsplit, int64_t* rps);
+bool ss_big_tn_ok(const FastGemm& p, int nsplit);
+int ss_big_tn_launch(FastGemm p, int nsplit, hipStream_t st);
 
 // Epilogue of the NT kernels: every lane turns its accumulators (TA x TB tiles of 32 x 32, transposed orientation: the lane
 // is output row `ml`, register quad g holds 4 consecutive columns) into bf16 cells of the LDS [m][n] image.  The activation

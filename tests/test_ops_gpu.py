@@ -76,7 +76,8 @@ def test_gemm_nt_bf16_fast_path(ops, M, N, K):
 
 
 @pytest.mark.parametrize('R,M,N', [(5000, 64, 64), (4097, 320, 1280), (9000, 512, 48 + 512), (1024, 128, 2048), (70, 8, 16), (3000, 1152, 320),
-                                   (70001, 6, 512), (333, 3, 1032)])
+                                   (70001, 6, 512), (333, 3, 1032),
+                                   (8192, 512, 256), (4096, 384, 512), (12288, 256, 328), (16384, 520, 768)])    # 256-tile kernel, ragged tiles
 def test_gemm_tn_bf16_fast_path(ops, R, M, N):
     dtype = torch.bfloat16
     a, b = rnd(R, M), rnd(R, N, seed=1)
@@ -90,7 +91,8 @@ def test_gemm_tn_bf16_fast_path(ops, R, M, N):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('R,M,N', [(5000, 64, 64), (70001, 320, 136), (9000, 512, 48 + 512), (300, 8, 16), (4097, 6, 512), (100000, 1280, 320)])
+@pytest.mark.parametrize('R,M,N', [(5000, 64, 64), (70001, 320, 136), (9000, 512, 48 + 512), (300, 8, 16), (4097, 6, 512), (100000, 1280, 320),
+                                   (8192, 512, 512), (4096, 328, 256)])
 def test_gemm_tn_with_bias_gradient(ops, dtype, R, M, N):
     """ss_gemm_tn_colsum: dW = dY^T X and db = column sums of dY from one pass (fused in the bf16 MFMA kernel, a second launch on
     the other paths); must agree with the two separate entry points."""
