@@ -258,6 +258,13 @@ int ss_image_affine(int out_dtype, const float* in, int64_t ldi, const float* M,
 int ss_adabound_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
                      float step_size, float lower, float upper, float weight_decay, float grad_scale, hipStream_t stream);
 
+/* ---- gradient delivery: dst[i][0..numel[i]) += src[i] for `count` fp32 tensors in one launch per 40 tensors.  Source i is
+ * numel[i] / cols[i] rows of cols[i] contiguous floats, src_ld[i] apart (cols[i] == numel[i]: contiguous); dst[i] is contiguous.
+ * src, src_ld, cols, dst and numel are HOST arrays.  Replaces autograd's per-parameter AccumulateGrad adds (what DDP's reducer
+ * does when it copies gradients into its buckets, train.py:306) when the gradients live in one flat buffer (engine.FlatParams). */
+int ss_multi_add_f32(int count, const float* const* src, const int64_t* src_ld, const int64_t* cols, float* const* dst,
+                     const int64_t* numel, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,12 +61,16 @@ class FlatParams:
                 self.data[o:o + p.numel()].copy_(p.detach().reshape(-1))
                 p.data = self.data[o:o + p.numel()].view(p.shape)
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                # the backward nodes of this package add their gradients straight into the slot (runtime.deliver_grads): one
+                # launch per node instead of one AccumulateGrad add per parameter
+                p._ss_grad_sink = p.grad
 
     def zero_grad(self):
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):           # a set_to_none elsewhere must not detach the views
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                p._ss_grad_sink = p.grad
 
 
 class GradReducer:
@@ -93,7 +97,8 @@ class GradReducer:
         self._hooks = []
         if self.world > 1:
             for i, p in enumerate(flat.params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))    # gradients that arrive through autograd
+                p._ss_grad_ready = self._make_hook(i)                                             # ... and through runtime.deliver_grads
 
     def _make_hook(self, i):
         def hook(_p):

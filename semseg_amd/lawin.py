@@ -17,7 +17,7 @@ from torch import nn, Tensor
 import torch.nn.functional as tnf
 
 from . import ops
-from .runtime import compute_dtype_for, as_tokens_nhwc
+from .runtime import compute_dtype_for, as_tokens_nhwc, deliver_grads
 from .segformer import w_fwd, w_bwd
 from .shapes import LAWIN_BRANCHES
 
@@ -207,7 +207,7 @@ class LawinHeadFn(torch.autograd.Function):
         B, hw = S['B'], S['hw']
         dfe = [(_nchw_view(d, B, h, w) if ctx.needs_input_grad[3 + i] else None) for i, (d, (h, w)) in enumerate(zip(dt, hw))]
         grads = [G.get(n) for n in ctx.names]
-        grads = [g if g is None else g.reshape(p.shape) for g, p in zip(grads, ctx.params)]
+        grads = deliver_grads(ctx.params, [g if g is None else g.reshape(p.shape) for g, p in zip(grads, ctx.params)])
         return (None, None, None, *dfe, *grads)
 
 

@@ -876,3 +876,38 @@ def image_affine(x, M, c, out_dtype=torch.float32, pre_act=0):
     code = {torch.float32: 0, torch.bfloat16: 1}[out_dtype]
     check(lib().ss_image_affine(code, _p(x), ldi, _p(M), _p(c), _p(out), mrows, rows // images, images, cin, mrows, pre_act, _stream()))
     return out
+
+
+# ---------------------------------------------------------------------------------- gradient delivery (engine.FlatParams)
+def multi_add_layout(t):
+    """-> (cols, ld) if `t` is a source ss_multi_add_f32 can read (contiguous, a strided 1-D vector, or 2-D rows with unit inner
+    stride), else None."""
+    if t.is_contiguous():
+        return t.numel(), t.numel()
+    if t.dim() == 1:
+        return 1, t.stride(0)
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t.shape[1], t.stride(0)
+    return None
+
+
+def multi_add(srcs, dsts):
+    """dsts[i] += srcs[i] for lists of fp32 device tensors (dsts contiguous, srcs as multi_add_layout allows), one launch per 40."""
+    import ctypes
+    n = len(srcs)
+    if n == 0:
+        return
+    lay = []
+    for s, d in zip(srcs, dsts):
+        _dev(s)
+        la = multi_add_layout(s)
+        if s.dtype != torch.float32 or d.dtype != torch.float32 or la is None or not d.is_contiguous() or s.numel() != d.numel() \
+                or s.numel() == 0 or s.device != d.device:
+            raise ValueError('multi_add: need float32 pairs of equal size on one device, contiguous destinations')
+        lay.append(la)
+    sp = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    dp = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    ne = (ctypes.c_int64 * n)(*[s.numel() for s in srcs])
+    co = (ctypes.c_int64 * n)(*[c for c, _ in lay])
+    ld = (ctypes.c_int64 * n)(*[l for _, l in lay])
+    check(lib().ss_multi_add_f32(n, sp, ld, co, dp, ne, _stream()))

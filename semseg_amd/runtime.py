@@ -47,3 +47,26 @@ def drop_path_keep(b, drop_prob, dtype, device):
     r = kp + torch.rand((b, 1, 1), dtype=dtype, device=device)
     r.floor_()
     return (r.float() / kp).reshape(b).contiguous()
+
+
+def deliver_grads(params, grads):
+    """What a backward node returns for its parameters.  A parameter that engine.FlatParams has given a slot in the flat
+    gradient buffer (``_ss_grad_sink``) receives its gradient there -- ALL such gradients of the node in one ``ss_multi_add_f32``
+    launch, with accumulate semantics like autograd's -- and autograd is handed None for it; its ``_ss_grad_ready`` callback
+    (the bucketed all-reduce of engine.GradReducer) fires once the launch is queued.  Everything else goes back to autograd."""
+    out, srcs, dsts, ready = [], [], [], []
+    for p, g in zip(params, grads):
+        sink = getattr(p, '_ss_grad_sink', None)
+        if g is None or sink is None or g.dtype != torch.float32 or g.numel() != sink.numel() or g.numel() == 0 \
+                or ops.multi_add_layout(g) is None or p.grad is None or p.grad.data_ptr() != sink.data_ptr():
+            out.append(g)
+            continue
+        srcs.append(g), dsts.append(sink), out.append(None)
+        cb = getattr(p, '_ss_grad_ready', None)
+        if cb is not None:
+            ready.append((cb, p))
+    if srcs:
+        ops.multi_add(srcs, dsts)
+        for cb, p in ready:
+            cb(p)
+    return out

@@ -10,7 +10,7 @@ import torch
 from torch import nn, Tensor
 
 from . import ops
-from .runtime import compute_dtype_for, as_tokens_nhwc, drop_path_keep
+from .runtime import compute_dtype_for, as_tokens_nhwc, drop_path_keep, deliver_grads
 from .shapes import MIT_VARIANTS, MIT_HEADS, MIT_SR, MIT_PATCH
 
 
@@ -145,7 +145,7 @@ class _ParamFn(torch.autograd.Function):
         dx, G = cls.bwd(P, ctx.S, dout.contiguous(), ctx.meta)
         ctx.S = None
         grads = [G.get(n) for n in ctx.names]
-        grads = [g if g is None else g.reshape(p.shape) for g, p in zip(grads, ctx.params)]
+        grads = deliver_grads(ctx.params, [g if g is None else g.reshape(p.shape) for g, p in zip(grads, ctx.params)])
         return (dx if ctx.needs_input_grad[0] else None, None, None, *grads)
 
 
