@@ -224,6 +224,48 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs, int nsplit
     }
 }
 
+// One launch for the whole split reduction: out = sum_z slab[z] (row-major MxN, leading dimension ldc) and, when the GEMM kernel
+// also left per-split column sums (cs_ws [nsplit][M], the fused bias gradient), colsum = sum_z cs_ws[z].  A block is COLS float4
+// columns x PARTS slab parts: thread (c, p) adds slabs p, p + PARTS, ... with independent loads, the parts meet in LDS and are
+// added in a fixed order (bitwise reproducible; PARTS depends only on the shape).  Replaces the two-level slab tree + the
+// separate column-sum reduce: three tiny launches per weight gradient became one.
+template <int PARTS>
+__global__ __launch_bounds__(256) void reduce_slabs_fused_kernel(const float* __restrict__ slabs, int nsplit, int64_t M, int N, float* __restrict__ out,
+                                                                 int64_t ldc, int accumulate, const float* __restrict__ cs_ws,
+                                                                 float* __restrict__ colsum, int cs_accumulate) {
+    constexpr int COLS = 256 / PARTS;
+    __shared__ floatx4 sh[PARTS][COLS + 1];
+    const int c = threadIdx.x % COLS, part = threadIdx.x / COLS;
+    const int64_t n = M * N, n4 = n / 4, m4 = cs_ws ? M / 4 : 0;
+    const int64_t col = (int64_t)blockIdx.x * COLS + c;
+    floatx4 s = {0.f, 0.f, 0.f, 0.f};
+    if (col < n4) {
+        const float* p = slabs + col * 4;
+#pragma unroll 4
+        for (int z = part; z < nsplit; z += PARTS) s += *(const floatx4*)(p + (int64_t)z * n);
+    } else if (col < n4 + m4) {
+        const float* p = cs_ws + (col - n4) * 4;
+#pragma unroll 4
+        for (int z = part; z < nsplit; z += PARTS) s += *(const floatx4*)(p + (int64_t)z * M);
+    }
+    sh[part][c] = s;
+    __syncthreads();
+    if (part != 0 || col >= n4 + m4) return;
+    floatx4 t = sh[0][c];
+#pragma unroll
+    for (int k = 1; k < PARTS; ++k) t += sh[k][c];
+    if (col < n4) {
+        const int64_t e = col * 4;
+        float* o = out + (e / N) * ldc + (e % N);
+        if (accumulate) t += *(const floatx4*)o;
+        *(floatx4*)o = t;
+    } else {
+        float* o = colsum + (col - n4) * 4;
+        if (cs_accumulate) { o[0] += t[0]; o[1] += t[1]; o[2] += t[2]; o[3] += t[3]; }
+        else { o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
+    }
+}
+
 // in-place first level of the slab tree: slab[g*group] = sum of slabs g*group .. g*group+group-1 (fixed order)
 __global__ void reduce_slabs_group_kernel(float* __restrict__ slabs, int nsplit, int group, int64_t n4) {
     const int g = blockIdx.y;
@@ -375,6 +417,23 @@ static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, in
         else return ss_fail(-1, "ss_gemm_tn: unsupported dtype %d", dtype);
     }
     SS_LAUNCH_CHECK();
+    const bool vec4 = N % 4 == 0 && ldc % 4 == 0 && aligned16(C);
+    if (vec4) {                                           // the common case: one launch reduces the slabs and the fused column sums
+        if (colsum && !cs_fused) {
+            int rc = ss_colsum(dtype, A, lda, R, (int)M, 1, 1.f, colsum, colsum_accumulate, cs_ws, kColsumWsRows * M * 4, stream);
+            if (rc) return rc;
+        }
+        const float* cw = colsum && cs_fused ? cs_ws : nullptr;
+        const int64_t cols = M * N / 4 + (cw ? M / 4 : 0);
+        if (ns > 16 || cols < 32768)
+            hipLaunchKernelGGL(reduce_slabs_fused_kernel<32>, dim3((unsigned)cdiv(cols, 8)), dim3(256), 0, stream, (const float*)workspace, ns, M, (int)N, C,
+                               ldc, accumulate, cw, colsum, colsum_accumulate);
+        else                                              // few slabs of a large output: a thread per float4 column adds them all
+            hipLaunchKernelGGL(reduce_slabs_fused_kernel<1>, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, stream, (const float*)workspace, ns, M, (int)N, C,
+                               ldc, accumulate, cw, colsum, colsum_accumulate);
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
     if (colsum) {
         if (cs_fused) {
             hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(M, 8), 1), dim3(256), 0, stream, (const float*)cs_ws, ns, (int)M, 1.f,
