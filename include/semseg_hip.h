@@ -137,6 +137,11 @@ int ss_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n,
 int ss_transpose_cast(int dst_dtype, const float* src, void* dst, int R, int Cc, int reverse_cols, hipStream_t stream);
 int ss_pack_conv_weight(int dst_dtype, const float* w, void* wp, void* wpt, int O, int I, int k, int Kp, hipStream_t stream);
 int ss_unpack_conv_wgrad(const float* gp, float* g, int O, int I, int k, int Kp, hipStream_t stream);
+/* ss_weight_prep_batch: the three conversions above for MANY weights in one launch.  table_dev: DEVICE array of nent entries of
+ * 8 int64 { src (fp32), dst, n_out, kind | dst_dtype << 8 | reverse_cols << 16, a, b, c, first_block }: kind 0 cast (n_out elements),
+ * 1 transpose_cast (a = R, b = Cc), 2 / 3 pack_conv_weight's wp / wpt (a = O, b = I, c = k | Kp << 32); an entry owns blocks
+ * first_block .. first_block + ceil(n_out / 1024) - 1 of the launch, total_blocks in all. */
+int ss_weight_prep_batch(const int64_t* table_dev, int nent, int64_t total_blocks, hipStream_t stream);
 int ss_nchw_to_nhwc(int dst_dtype, const float* x, void* y, int B, int C, int64_t HW, hipStream_t stream);
 int ss_add(int dtype, const void* a, const void* b, void* out, int64_t n, hipStream_t stream);
 int ss_rowscale(int dtype, const void* x, const float* scale, int64_t rows_per_scale, void* out, int64_t rows, int C, hipStream_t stream);

@@ -13,7 +13,8 @@ from torch import nn, Tensor
 
 from . import ops
 from .runtime import compute_dtype_for, as_tokens_nhwc, drop_path_keep
-from .segformer import _ParamFn, w_fwd, w_bwd, linear_grads
+from .segformer import _ParamFn, w_fwd, w_bwd, w_taps, linear_grads
+from . import weightprep
 from .helpers import DropPath
 
 CONVNEXT_VARIANTS = {                       # modules/convnext.py:72-77  [depths, dims, drop-path rate]
@@ -49,7 +50,7 @@ class _PatchConvFn(_ParamFn):
     def fwd(P, x, meta):
         B, H, W, Cin, k = meta
         col, ho, wo = ops.im2col(x, B, H, W, Cin, k, k, 0)
-        wp, _ = ops.pack_conv_weight(P['weight'].detach(), x.dtype, transposed=False)
+        wp = weightprep.pack(P['weight'], x.dtype)
         return ops.gemm_nt(col, wp, bias=P['bias']), {'col': col}
 
     @staticmethod
@@ -59,7 +60,7 @@ class _PatchConvFn(_ParamFn):
         G = {'bias': db, 'weight': ops.unpack_conv_wgrad(gp, dy.shape[1], Cin, k)}
         dx = None
         if Cin % 8 == 0:                                     # the RGB image needs no gradient
-            _, wpt = ops.pack_conv_weight(P['weight'].detach(), dy.dtype, transposed=True)
+            wpt = weightprep.pack(P['weight'], dy.dtype, transposed=True)
             dx = ops.col2im(ops.gemm_nt(dy, wpt), B, H, W, Cin, k, k, 0)
         return dx, G
 
@@ -70,7 +71,7 @@ class _BlockFn(_ParamFn):
         B, h, w, keep = meta
         T = x.dtype
         C = x.shape[1]
-        w49 = ops.transpose_cast(P['dw_conv.weight'].detach().reshape(C, 49), torch.float32)
+        w49 = w_taps(P['dw_conv.weight'])
         d = ops.dwconvk_fwd(x, w49, P['dw_conv.bias'], B, h, w, 7)
         n, m, r = ops.layernorm_fwd(d, P['norm.weight'], P['norm.bias'], 1e-6)
         z1 = ops.gemm_nt(n, w_fwd(P['pw_conv1.weight'], T), bias=P['pw_conv1.bias'])
@@ -108,7 +109,7 @@ class _BlockFn(_ParamFn):
         dwdb = ops.dwconvk_wgrad(dd, S['x'], B, h, w, 7)
         G['dw_conv.weight'] = ops.transpose_cast(dwdb[:49].contiguous(), torch.float32).reshape(C, 1, 7, 7)
         G['dw_conv.bias'] = dwdb[49]
-        flip = ops.transpose_cast(P['dw_conv.weight'].detach().reshape(C, 49), torch.float32, reverse_cols=True)
+        flip = w_taps(P['dw_conv.weight'], reverse=True)
         dx = ops.add(ops.dwconvk_fwd(dd, flip, None, B, h, w, 7), dout)
         return dx, G
 

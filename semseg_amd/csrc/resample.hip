@@ -35,6 +35,34 @@ __global__ __launch_bounds__(256) void im2col_scalar_kernel(const T* __restrict_
         col[i] = from_f<T>(v);
     }
 }
+// narrow inputs (the 3-channel image under patch_embed1's 7x7 / 4): a thread gathers 8 consecutive k*k*C entries of one output
+// pixel (2- or 4-byte loads, served by L1: neighbouring taps share lines) and writes them as one 16-byte store.
+// grid: (B*ho output rows, blocks over wo * Kp/8)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_narrow_kernel(const T* __restrict__ x, T* __restrict__ col, int H, int W, int C,
+                                                            int k, int s, int pad, int ho, int wo, int Kp, FastDiv dchunks, FastDiv dC, FastDiv dk) {
+    const unsigned chunks = dchunks.d;
+    const unsigned idx = blockIdx.y * 256u + threadIdx.x;
+    if (idx >= (unsigned)wo * chunks) return;
+    const unsigned row = blockIdx.x, b = row / (unsigned)ho, oy = row - b * ho;
+    const unsigned ox = fdiv(idx, dchunks), ch = idx - ox * chunks;
+    const int kkC = k * k * C;
+    const int y0 = (int)oy * s - pad, x0 = (int)ox * s - pad;
+    const T* img = x + (int64_t)b * H * W * C;
+    F8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned kc = ch * 8 + e;
+        const unsigned tap = fdiv(kc, dC), c = kc - tap * C;
+        const unsigned ky = fdiv(tap, dk), kx = tap - ky * k;
+        const int iy = y0 + (int)ky, ix = x0 + (int)kx;
+        const bool ok = (int)kc < kkC && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const int64_t off = ok ? ((int64_t)iy * W + ix) * C + c : 0;
+        const float f = to_f(img[off]);
+        v.v[e] = ok ? f : 0.f;
+    }
+    store8(col + ((int64_t)row * wo + ox) * Kp + ch * 8, v);
+}
 // gather form: every input pixel sums the taps that read it (deterministic).  grid: (B*H input rows, blocks over W * C/8)
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ col, T* __restrict__ dx, int H, int W, int C,
@@ -75,6 +103,11 @@ extern "C" int ss_im2col(int dtype, const void* x, void* col, int B, int H, int 
         dim3 grid((unsigned)(B * ho), (unsigned)cdiv(per_row, 256));
         SS_DISPATCH(dtype, hipLaunchKernelGGL((im2col_vec_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, (T*)col, H, W, C, k, s, pad, ho, wo,
                                               fast_div(C / 8), fast_div(k * k * (C / 8)), fast_div(k)));
+    } else if (Kp % 8 == 0 && aligned16(col) && (int64_t)wo * (Kp / 8) < (1LL << 31) && cdiv((int64_t)wo * (Kp / 8), 256) < 65536 &&
+               (int64_t)B * ho < (1LL << 31)) {
+        dim3 grid((unsigned)(B * ho), (unsigned)cdiv((int64_t)wo * (Kp / 8), 256));
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((im2col_narrow_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, (T*)col, H, W, C, k, s, pad, ho, wo, Kp,
+                                              fast_div(Kp / 8), fast_div(C), fast_div(k)));
     } else {
         int64_t total = (int64_t)B * ho * wo * Kp;
         int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
@@ -382,6 +415,57 @@ extern "C" int ss_bcast_rows(int dtype, const void* v, void* y, int64_t ldy, int
     SS_CHECK(v && y && rows > 0 && C > 0 && C % 8 == 0 && ldy >= C && ldy % 8 == 0 && rows_per_image > 0, "ss_bcast_rows: bad arguments");
     dim3 g(nblocks(rows * (C / 8), 16384)), b(256);
     SS_DISPATCH(dtype, hipLaunchKernelGGL((bcast_rows_kernel<T>), g, b, 0, stream, (const T*)v, (T*)y, ldy, rows_per_image, rows, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ all of a model's weight conversions in one launch
+// The per-step casts / transposes / conv-weight packings of the fp32 master weights (ss_cast, ss_transpose_cast,
+// ss_pack_conv_weight: ~280 launches of ~5 us each per MiT-B2 + Lawin step) replayed from a table that lives in device memory:
+// entry e = { src, dst, n_out, kind | dst_dtype << 8 | reverse << 16, a, b, c, first_block } (8 x int64), element formulas
+// identical to the single-tensor kernels above.  A block owns 1024 consecutive output elements of one entry.
+//   kind 0 cast            dst[i] = src[i]
+//   kind 1 transpose_cast  src [a = R][b = Cc] -> dst [Cc][R]
+//   kind 2 pack (wp)       src [a = O][b = I][k][k] -> dst [O][Kp], c = k | Kp << 32
+//   kind 3 pack (wpt)      same source -> dst [Kp][O]
+template <typename TO>
+__device__ __forceinline__ void prep_block(const int64_t* __restrict__ ent, int64_t base) {
+    const float* __restrict__ src = (const float*)ent[0];
+    TO* __restrict__ dst = (TO*)ent[1];
+    const int64_t n = ent[2];
+    const int kind = (int)(ent[3] & 0xff), reverse = (int)((ent[3] >> 16) & 1);
+    const int a = (int)ent[4], b = (int)ent[5], k = (int)(ent[6] & 0xffffffff), Kp = (int)(ent[6] >> 32);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        if (i >= n) break;
+        float v;
+        if (kind == 0) v = src[i];
+        else if (kind == 1) { const int c = (int)(i / a), r = (int)(i % a); v = src[(int64_t)r * b + (reverse ? b - 1 - c : c)]; }
+        else {
+            int o, kc;
+            if (kind == 2) { o = (int)(i / Kp); kc = (int)(i % Kp); } else { kc = (int)(i / a); o = (int)(i % a); }
+            v = 0.f;
+            if (kc < k * k * b) { const int ci = kc % b, tap = kc / b; v = src[(((int64_t)o * b + ci) * k + tap / k) * k + tap % k]; }
+        }
+        dst[i] = from_f<TO>(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const int64_t* __restrict__ table, int nent) {
+    int lo = 0, hi = nent - 1;                         // last entry whose first_block <= blockIdx.x (wave-uniform search)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(int64_t)mid * 8 + 7] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* ent = table + (int64_t)lo * 8;
+    const int64_t base = ((int64_t)blockIdx.x - ent[7]) * 1024;
+    if (((ent[3] >> 8) & 0xff) == SS_BF16) prep_block<bf16>(ent, base); else prep_block<float>(ent, base);
+}
+
+extern "C" int ss_weight_prep_batch(const int64_t* table_dev, int nent, int64_t total_blocks, hipStream_t stream) {
+    SS_CHECK(table_dev && nent > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "ss_weight_prep_batch: bad arguments");
+    hipLaunchKernelGGL(weight_prep_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, table_dev, nent);
     SS_LAUNCH_CHECK();
     return 0;
 }

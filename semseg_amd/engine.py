@@ -16,7 +16,7 @@ import math
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import ops, weightprep
 from ._lib import lib, check
 
 
@@ -56,6 +56,7 @@ class FlatParams:
         self.data = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.params, self.offsets = order, offs
+        weightprep.clear()                                     # the parameters move: remembered weight copies point at the old storage
         with torch.no_grad():
             for p, o in zip(order, offs):
                 self.data[o:o + p.numel()].copy_(p.detach().reshape(-1))
@@ -149,6 +150,7 @@ def broadcast_module_state(model, src=0):
                 t.data.copy_(h)
             else:
                 dist.broadcast(t.data, src)
+    weightprep.bump()
 
 
 class AdaBound:
@@ -177,3 +179,4 @@ class AdaBound:
         check(lib().ss_adabound_step(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                      f.numel, self.betas[0], self.betas[1], self.eps, step_size, lower, upper, self.wd,
                                      grad_scale, torch.cuda.current_stream().cuda_stream))
+        weightprep.bump()                                      # the kernel wrote the parameters through a raw pointer

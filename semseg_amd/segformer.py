@@ -9,21 +9,27 @@ compute dtype (fp32, or bf16 with fp32 accumulation / statistics / parameters).
 import torch
 from torch import nn, Tensor
 
-from . import ops
+from . import ops, weightprep
 from .runtime import compute_dtype_for, as_tokens_nhwc, drop_path_keep, deliver_grads
 from .shapes import MIT_VARIANTS, MIT_HEADS, MIT_SR, MIT_PATCH
 
 
 # ------------------------------------------------------------------ weight preparation (cast / repack per step)
 def w_fwd(w, dtype):
-    """nn.Linear weight [N, K] fp32 -> compute dtype (no copy in fp32)."""
-    w2 = w.detach().reshape(w.shape[0], -1)
-    return w2 if dtype == torch.float32 else ops.cast(w2.contiguous(), dtype)
+    """nn.Linear / 1x1 conv weight [N, K, ...] fp32 -> [N, K] in the compute dtype (the fp32 view itself in fp32)."""
+    return weightprep.cast(w, dtype)
 
 
 def w_bwd(w, dtype):
     """[N, K] -> [K, N] in the compute dtype: the B operand of the data-gradient GEMM."""
-    return ops.transpose_cast(w.detach().reshape(w.shape[0], -1).contiguous(), dtype)
+    n = w.shape[0]
+    return weightprep.transpose(w, n, w.numel() // n, dtype)
+
+
+def w_taps(w, dtype=torch.float32, reverse=False):
+    """depthwise conv weight [C, 1, k, k] -> tap-major [k*k, C] (taps reversed for the data gradient)."""
+    c = w.shape[0]
+    return weightprep.transpose(w, c, w.numel() // c, dtype, reverse_cols=reverse)
 
 
 def linear_grads(dout, x_in, want_bias=True):
@@ -43,7 +49,7 @@ def attn_forward(P, x, B, h, w, head, sr, res=None, keep=None):
     q = ops.gemm_nt(x, w_fwd(P['q.weight'], T), bias=P['q.bias'])
     if sr > 1:
         col, ho, wo = ops.im2col(x, B, h, w, C, sr, sr, 0)
-        wp, _ = ops.pack_conv_weight(P['sr.weight'].detach(), T, transposed=False)
+        wp = weightprep.pack(P['sr.weight'], T)
         s = ops.gemm_nt(col, wp, bias=P['sr.bias'])
         xr, m, r = ops.layernorm_fwd(s, P['norm.weight'], P['norm.bias'], 1e-5)
         S.update(col=col, s=s, m=m, r=r)
@@ -73,7 +79,7 @@ def attn_backward(P, S, dout, B, h, w, head, sr):
         G['norm.weight'], G['norm.bias'] = dgb[0], dgb[1]
         gp, G['sr.bias'] = ops.gemm_tn(ds, S['col'], colsum=True)
         G['sr.weight'] = ops.unpack_conv_wgrad(gp, C, C, sr)
-        _, wpt = ops.pack_conv_weight(P['sr.weight'].detach(), T, transposed=True)
+        wpt = weightprep.pack(P['sr.weight'], T, transposed=True)
         dxa = ops.col2im(ops.gemm_nt(ds, wpt), B, h, w, C, sr, sr, 0)
     else:
         dxa = dxr
@@ -87,7 +93,7 @@ def mlp_forward(P, x, B, h, w, res=None, keep=None):
     T = x.dtype
     h1 = ops.gemm_nt(x, w_fwd(P['fc1.weight'], T), bias=P['fc1.bias'])
     Ch = h1.shape[1]
-    w9c = ops.transpose_cast(P['dw_conv.dw_conv.weight'].detach().reshape(Ch, 9), torch.float32)
+    w9c = w_taps(P['dw_conv.dw_conv.weight'])
     a2 = ops.dwconv3_fwd(h1, w9c, P['dw_conv.dw_conv.bias'], B, h, w, act=1)
     out = ops.gemm_nt(a2, w_fwd(P['fc2.weight'], T), bias=P['fc2.bias'], res=res, rowscale=keep,
                       rows_per_scale=h * w if keep is not None else 0)
@@ -103,7 +109,7 @@ def mlp_backward(P, S, dout, B, h, w):
     g, dwdb = ops.dwconv3_bwd(da2, S['h1'], S['w9c'], P['dw_conv.dw_conv.bias'], B, h, w, act=1)
     G['dw_conv.dw_conv.weight'] = ops.transpose_cast(dwdb[:9], torch.float32).reshape(Ch, 1, 3, 3)
     G['dw_conv.dw_conv.bias'] = dwdb[9]
-    w9c_flip = ops.transpose_cast(P['dw_conv.dw_conv.weight'].detach().reshape(Ch, 9), torch.float32, reverse_cols=True)
+    w9c_flip = w_taps(P['dw_conv.dw_conv.weight'], reverse=True)
     dh1 = ops.dwconv3_fwd(g, w9c_flip, None, B, h, w, act=0)
     G['fc1.weight'], G['fc1.bias'] = linear_grads(dh1, S['x'])
     dx = ops.gemm_nt(dh1, w_bwd(P['fc1.weight'], T))
@@ -219,7 +225,7 @@ class PatchEmbedFn(_ParamFn):
         B, H, W, Cin, k, s = meta
         T = x.dtype
         col, ho, wo = ops.im2col(x, B, H, W, Cin, k, s, k // 2)
-        wp, _ = ops.pack_conv_weight(P['proj.weight'].detach(), T, transposed=False)
+        wp = weightprep.pack(P['proj.weight'], T)
         z = ops.gemm_nt(col, wp, bias=P['proj.bias'])
         y, m, r = ops.layernorm_fwd(z, P['norm.weight'], P['norm.bias'], 1e-5)
         return y, {'col': col, 'z': z, 'm': m, 'r': r}
@@ -235,7 +241,7 @@ class PatchEmbedFn(_ParamFn):
         G['proj.weight'] = ops.unpack_conv_wgrad(gp, Cout, Cin, k)
         dx = None
         if Cin % 8 == 0:                                      # the RGB image (stage 1) needs no gradient
-            _, wpt = ops.pack_conv_weight(P['proj.weight'].detach(), T, transposed=True)
+            wpt = weightprep.pack(P['proj.weight'], T, transposed=True)
             dx = ops.col2im(ops.gemm_nt(dz, wpt), B, H, W, Cin, k, s, k // 2)
         return dx, G
 
@@ -294,7 +300,7 @@ class DWConvFn(_ParamFn):
     def fwd(P, x, meta):
         B, h, w = meta
         C = x.shape[1]
-        w9c = ops.transpose_cast(P['dw_conv.weight'].detach().reshape(C, 9), torch.float32)
+        w9c = w_taps(P['dw_conv.weight'])
         return ops.dwconv3_fwd(x, w9c, P['dw_conv.bias'], B, h, w, act=0), {'x': x, 'w9c': w9c}
 
     @staticmethod
@@ -302,7 +308,7 @@ class DWConvFn(_ParamFn):
         B, h, w = meta
         C = dy.shape[1]
         g, dwdb = ops.dwconv3_bwd(dy, S['x'], S['w9c'], P['dw_conv.bias'], B, h, w, act=0)
-        flip = ops.transpose_cast(P['dw_conv.weight'].detach().reshape(C, 9), torch.float32, reverse_cols=True)
+        flip = w_taps(P['dw_conv.weight'], reverse=True)
         dx = ops.dwconv3_fwd(g, flip, None, B, h, w, act=0)
         return dx, {'dw_conv.weight': ops.transpose_cast(dwdb[:9], torch.float32).reshape(C, 1, 3, 3), 'dw_conv.bias': dwdb[9]}
 
