@@ -145,6 +145,9 @@ int ss_weight_prep_batch(const int64_t* table_dev, int nent, int64_t total_block
 int ss_nchw_to_nhwc(int dst_dtype, const float* x, void* y, int B, int C, int64_t HW, hipStream_t stream);
 int ss_add(int dtype, const void* a, const void* b, void* out, int64_t n, hipStream_t stream);
 int ss_rowscale(int dtype, const void* x, const float* scale, int64_t rows_per_scale, void* out, int64_t rows, int C, hipStream_t stream);
+/* ss_droppath_keep: keep[i] = floor(keep_prob + u[i]) / keep_prob for the torch.rand draw u (activation dtype; the sum is rounded
+ * to it first), modules/helpers.py:20-24 -- the fp32 per-sample multiplier handed to ss_gemm_nt's rowscale. */
+int ss_droppath_keep(int dtype, const void* u, float keep_prob, float* keep, int n, hipStream_t stream);
 int ss_bcast_rows(int dtype, const void* v, void* y, int64_t ldy, int64_t rows_per_image, int64_t rows, int C, hipStream_t stream);
 
 /* ---- Lawin large-window attention (modules/lawin.py:18-94,140-179).  feat: [B,H,W,C] channels-last (H,W multiples of 8).

@@ -469,3 +469,20 @@ extern "C" int ss_weight_prep_batch(const int64_t* table_dev, int nent, int64_t 
     SS_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------ DropPath multiplier (modules/helpers.py:17-24)
+// keep[i] = floor(kp + u[i]) / kp with u the torch.rand draw in the activation dtype: the sum is rounded to that dtype before the
+// floor, as `kp + torch.rand(shape, dtype=x.dtype)` does, and the division is torch's scalar form (a multiply by 1 / kp in fp32).
+// One launch instead of add, floor_, float and div.
+template <typename T>
+__global__ void droppath_keep_kernel(const T* __restrict__ u, float kp, float inv_kp, float* __restrict__ keep, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keep[i] = floorf(to_f(from_f<T>(kp + to_f(u[i])))) * inv_kp;
+}
+extern "C" int ss_droppath_keep(int dtype, const void* u, float keep_prob, float* keep, int n, hipStream_t stream) {
+    SS_CHECK(u && keep && n > 0 && keep_prob > 0.f && keep_prob <= 1.f, "ss_droppath_keep: bad arguments (keep_prob=%f)", (double)keep_prob);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((droppath_keep_kernel<T>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, (const T*)u, keep_prob,
+                                          1.0f / keep_prob, keep, n));
+    SS_LAUNCH_CHECK();
+    return 0;
+}

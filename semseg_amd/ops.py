@@ -911,3 +911,13 @@ def multi_add(srcs, dsts):
     co = (ctypes.c_int64 * n)(*[c for c, _ in lay])
     ld = (ctypes.c_int64 * n)(*[l for _, l in lay])
     check(lib().ss_multi_add_f32(n, sp, ld, co, dp, ne, _stream()))
+
+
+def droppath_keep(u, keep_prob):
+    """u: torch.rand draw [b, ...] in the activation dtype -> fp32 [b] multipliers floor(kp + u) / kp."""
+    _dev(u)
+    if not u.is_contiguous():
+        raise ValueError('droppath_keep: u must be contiguous')
+    out = torch.empty(u.numel(), dtype=torch.float32, device=u.device)
+    check(lib().ss_droppath_keep(dt(u), _p(u), float(keep_prob), _p(out), u.numel(), _stream()))
+    return out

@@ -44,9 +44,7 @@ def drop_path_keep(b, drop_prob, dtype, device):
     """Per-sample DropPath multiplier floor(kp + U[0,1)) / kp drawn exactly like modules/helpers.py:20-24 (same torch RNG
     call, shape and dtype), returned as fp32 [B] for the GEMM epilogue."""
     kp = 1 - drop_prob
-    r = kp + torch.rand((b, 1, 1), dtype=dtype, device=device)
-    r.floor_()
-    return (r.float() / kp).reshape(b).contiguous()
+    return ops.droppath_keep(torch.rand((b, 1, 1), dtype=dtype, device=device), kp)
 
 
 def deliver_grads(params, grads):

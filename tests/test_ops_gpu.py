@@ -366,3 +366,13 @@ def test_lawin_position_mixing(ops, dtype, C, heads, r):
     refW = torch.einsum('wqhc,wphc->hqp', dq, xw)
     assert rel(dWb[:, :, :64], refW) < tol
     assert rel(dWb[:, :, 64], dq.sum((0, 3)).t()) < tol
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_droppath_keep_matches_torch_ops(ops, dtype):
+    """modules/helpers.py:20-24 as torch runs it: kp + rand (rounded to the dtype), floor_, then / kp."""
+    for kp in (0.9, 0.9667, 0.5, 1.0):
+        u = torch.rand((4096, 1, 1), device='cuda').to(dtype)
+        want = (kp + u).floor_().float() / kp
+        got = ops.droppath_keep(u, kp)
+        assert got.shape == (4096,) and torch.equal(got, want.reshape(-1))
