@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* _
 // ------------------------------------------------------------------ backward: dQ (lane = query)
 template <int D>
 __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dq_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kv,
-        const bf16* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta, bf16* __restrict__ dq,
-        int N, int Np, int Nk, int heads, int C, float c, float scale) {
+        const bf16* __restrict__ dout, const bf16* __restrict__ o, const float* __restrict__ lse, float* __restrict__ delta,
+        bf16* __restrict__ dq, int N, int Np, int Nk, int heads, int C, float c, float scale) {
     typedef AttnCfg<D> G;
     constexpr int CH = G::CH, NCH = G::NCH, PT = G::PT;
     constexpr int STG = 2 * G::SW + G::TR;
@@ -178,7 +178,18 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dq_bf16_kernel(const bf16
         qf[s] = *(const bf16x8*)(q + ((int64_t)b * N + qrow) * C + hd * D + 16 * s + 8 * h);
         dof[s] = *(const bf16x8*)(dout + ((int64_t)b * N + qrow) * C + hd * D + 16 * s + 8 * h);
     }
-    const float ls = lse[(int64_t)(b * heads + hd) * Np + qrow], dls = delta[(int64_t)(b * heads + hd) * Np + qrow] * scale;
+    // delta = rowsum(dO * O) of this query, computed here from the dO fragment already in registers (each lane half holds 32 of the
+    // D values) and left in `delta` for the dK/dV kernel that follows on the stream
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) {
+        const bf16x8 of = *(const bf16x8*)(o + ((int64_t)b * N + qrow) * C + hd * D + 16 * s + 8 * h);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl = fmaf((float)dof[s][e], (float)of[e], dl);
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    if (h == 0 && q0 + j < N) delta[(int64_t)(b * heads + hd) * Np + q0 + j] = dl;
+    const float ls = lse[(int64_t)(b * heads + hd) * Np + qrow], dls = dl * scale;
     const bf16* kbase = kv + (int64_t)b * Nk * 2 * C + hd * D;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     bf16x8 rk[NCH], rv[NCH];
@@ -376,7 +387,7 @@ int attn_fwd_bf16_launch(const AttnBf16Args& a, hipStream_t stream) {
 }
 template <int D> static void bwd_launch(const AttnBf16Args& a, hipStream_t st) {
     dim3 gq((unsigned)cdiv(a.N, 128), a.heads, a.B), gk((unsigned)cdiv(a.Nkp, 128), a.heads, a.B * a.ns);
-    hipLaunchKernelGGL((mit_attn_bwd_dq_bf16_kernel<D>), gq, dim3(256), 0, st, a.q, a.kv, a.dout, a.lse, a.delta, a.dq, a.N, a.Np, a.Nk,
+    hipLaunchKernelGGL((mit_attn_bwd_dq_bf16_kernel<D>), gq, dim3(256), 0, st, a.q, a.kv, a.dout, a.o, a.lse, a.delta, a.dq, a.N, a.Np, a.Nk,
                        a.heads, a.C, a.c, a.scale);
     hipLaunchKernelGGL((mit_attn_bwd_dkv_bf16_kernel<D>), gk, dim3(256), 0, st, a.q, a.dout, a.kv, a.lse, a.delta, a.dks, a.dvs, a.B, a.N,
                        a.Np, a.Nk, a.Nkp, a.heads, a.C, a.c, a.scale, a.ns, a.qps);

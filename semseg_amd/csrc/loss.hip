@@ -52,6 +52,83 @@ __global__ __launch_bounds__(256) void ce_prob_kernel(const T* __restrict__ logi
     if (threadIdx.x == 0 && sh[0]) atomicAdd((unsigned long long*)&ctl->num_valid, (unsigned long long)sh[0]);
 }
 
+// ---- channels-last fast path (what the networks of this package return: pixel-major, C <= 8 contiguous channels per pixel, `pitch`
+// elements apart): the pixel's logits are loaded once into registers (4-byte pairs for bf16) and no index is divided.
+template <typename T>
+__device__ __forceinline__ void load_pixel(const T* __restrict__ p, int C, bool pairs, float (&v)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = -INFINITY;
+    if (pairs) {
+#pragma unroll
+        for (int c = 0; c < 8; c += 2)
+            if (c < C) { const bf16x2 t = *(const bf16x2*)((const bf16*)p + c); v[c] = (float)t[0]; v[c + 1] = (float)t[1]; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < C) v[c] = to_f(p[c]);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_prob_cl_kernel(const T* __restrict__ logits, int64_t pitch, const long long* __restrict__ labels,
+        float* __restrict__ prob, float* __restrict__ nll, unsigned* __restrict__ vkey, OhemCtl* ctl, int64_t npix, int C, long long ignore, int pairs) {
+    long long nv = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8]; load_pixel(logits + i * pitch, C, pairs != 0, v);
+        const long long lab = labels[i];
+        float mx = v[0];
+#pragma unroll
+        for (int c = 1; c < 8; ++c) mx = fmaxf(mx, v[c]);
+        float sum = 0.f, zl = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < C) { sum += expf(v[c] - mx); if (c == lab) zl = v[c] - mx; }
+        float pr = 0.f, nl = 0.f;
+        if (lab >= 0 && lab < C) { nl = logf(sum) - zl; pr = expf(zl) / sum; }
+        const bool valid = lab != ignore;
+        prob[i] = pr; nll[i] = nl; vkey[i] = valid ? __float_as_uint(pr) : 0xFFFFFFFFu;
+        nv += valid;
+    }
+    __shared__ long long sh[256];
+    sh[threadIdx.x] = nv; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0 && sh[0]) atomicAdd((unsigned long long*)&ctl->num_valid, (unsigned long long)sh[0]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_cl_kernel(const T* __restrict__ logits, int64_t pitch, const long long* __restrict__ labels,
+        const float* __restrict__ prob, const OhemCtl* ctl, const float* __restrict__ gout, T* __restrict__ dlogits, int64_t opitch,
+        int64_t npix, int C, long long ignore, int pairs) {
+    const int sel = ctl->do_select; const float thr = ctl->thr;
+    const float g = gout[0] / (float)ctl->kept;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long lab = labels[i];
+        const bool keep = lab != ignore && (!sel || prob[i] < thr);
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = 0.f;
+        if (keep) {
+            float v[8]; load_pixel(logits + i * pitch, C, pairs != 0, v);
+            float mx = v[0];
+#pragma unroll
+            for (int c = 1; c < 8; ++c) mx = fmaxf(mx, v[c]);
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) if (c < C) { v[c] = expf(v[c] - mx); sum += v[c]; }
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) if (c < C) o[c] = g * (v[c] * inv - (c == lab ? 1.f : 0.f));
+        }
+        T* d = dlogits + i * opitch;
+        if (pairs) {
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) if (c < C) { bf16x2 t = {(bf16)o[c], (bf16)o[c + 1]}; *(bf16x2*)((bf16*)d + c) = t; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) if (c < C) d[c] = from_f<T>(o[c]);
+        }
+    }
+}
+static inline bool ce_channels_last(int64_t sn, int64_t sc, int64_t sh, int64_t sw, int C, int H, int W) {
+    return sc == 1 && C <= 8 && sw >= C && sh == (int64_t)W * sw && sn == (int64_t)H * sh;
+}
+
 __global__ void ohem_plan_kernel(OhemCtl* ctl, double min_kept) {
     const long long nv = ctl->num_valid;
     const long long k = (long long)(min_kept * (double)nv);          // int(self.min_kept * valid_prob.numel())
@@ -80,14 +157,29 @@ __global__ __launch_bounds__(256) void ohem_hist_kernel(const unsigned* __restri
     __syncthreads();
     for (int i = threadIdx.x; i < OHEM_BINS; i += blockDim.x) if (sh[i]) atomicAdd(&hist[i], sh[i]);
 }
-__global__ void ohem_scan_kernel(OhemCtl* ctl, const unsigned* __restrict__ hist, int pass) {
+// one block of 256 threads: thread t owns bins 8t .. 8t+7; block-wide exclusive scan of the per-thread totals, then the owner of the
+// bin where the running count first reaches krem records it (the serial walk over 2048 bins took 60 us per pass)
+__global__ __launch_bounds__(256) void ohem_scan_kernel(OhemCtl* ctl, const unsigned* __restrict__ hist, int pass) {
     if (!ctl->do_select) return;
     int shift; unsigned mask, himask; pass_bits(pass, shift, mask, himask);
-    long long rem = ctl->krem, cum = 0;
-    for (unsigned b = 0; b <= mask; ++b) {
-        const long long h = hist[b];
-        if (cum + h >= rem) { ctl->prefix |= b << shift; ctl->krem = rem - cum; return; }
-        cum += h;
+    __shared__ long long tot[256];
+    const int t = threadIdx.x;
+    const long long rem = ctl->krem;
+    const unsigned prefix = ctl->prefix;
+    unsigned h[8]; long long mine = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const unsigned b = t * 8 + e; h[e] = b <= mask ? hist[b] : 0u; mine += h[e]; }
+    tot[t] = mine;
+    __syncthreads();
+    long long before = 0;
+    for (int u = 0; u < t; ++u) before += tot[u];
+    if (before < rem && before + mine >= rem) {              // exactly one thread: the running count crosses krem inside its bins
+        long long cum = before;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (cum + h[e] >= rem) { ctl->prefix = prefix | ((unsigned)(t * 8 + e) << shift); ctl->krem = rem - cum; break; }
+            cum += h[e];
+        }
     }
 }
 // per chunk of OHEM_CHUNK pixels: number of valid pixels and of valid pixels whose key equals the selected value
@@ -126,23 +218,38 @@ __global__ __launch_bounds__(1024) void ohem_locate_chunk_kernel(OhemCtl* ctl, c
         ctl->chunk = -1;
     }
 }
-// one thread walks the located chunk (4096 keys), applies the reference's index quirk and updates the stateful threshold
-__global__ void ohem_threshold_kernel(OhemCtl* ctl, const unsigned* __restrict__ vkey, const float* __restrict__ prob, int64_t npix,
-                                      float* __restrict__ thr_state) {
-    if (ctl->do_select && ctl->chunk >= 0) {
+// one block walks the located chunk (4096 keys, 16 consecutive keys per thread): finds the position of the needed occurrence of
+// the selected value, applies the reference's index quirk and updates the stateful threshold
+__global__ __launch_bounds__(256) void ohem_threshold_kernel(OhemCtl* ctl, const unsigned* __restrict__ vkey, const float* __restrict__ prob, int64_t npix,
+                                                             float* __restrict__ thr_state) {
+    __shared__ int seq[256], sval[256];
+    const int t = threadIdx.x;
+    const bool active = ctl->do_select && ctl->chunk >= 0;
+    if (active) {
         const unsigned target = ctl->prefix;
-        long long need = ctl->krem - ctl->eq_before, j = ctl->valid_before;
-        const int64_t base = (int64_t)ctl->chunk * OHEM_CHUNK;
-        for (int e = 0; e < OHEM_CHUNK && base + e < npix; ++e) {
-            const unsigned key = vkey[base + e];
-            if (key == target && --need == 0) break;
-            j += key != 0xFFFFFFFFu;
+        const long long need = ctl->krem - ctl->eq_before;          // 1-based occurrence inside the chunk
+        const int64_t base = (int64_t)ctl->chunk * OHEM_CHUNK + t * 16;
+        unsigned key[16]; int ne = 0, nv = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { key[e] = base + e < npix ? vkey[base + e] : 0xFFFFFFFFu; ne += key[e] == target; nv += key[e] != 0xFFFFFFFFu; }
+        seq[t] = ne; sval[t] = nv;
+        __syncthreads();
+        long long eq_before = 0, valid_before = 0;
+        for (int u = 0; u < t; ++u) { eq_before += seq[u]; valid_before += sval[u]; }
+        if (eq_before < need && eq_before + ne >= need) {          // the occurrence lies in this thread's 16 keys
+            long long left = need - eq_before, j = ctl->valid_before + valid_before;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (key[e] == target && --left == 0) break;
+                j += key[e] != 0xFFFFFFFFu;
+            }
+            ctl->j = j;
+            const float cand = prob[j];           // sic: index among the valid pixels applied to the all-pixel vector
+            if (cand > *thr_state) *thr_state = cand;
         }
-        ctl->j = j;
-        const float cand = prob[j];               // sic: index among the valid pixels applied to the all-pixel vector
-        if (cand > *thr_state) *thr_state = cand;
     }
-    ctl->thr = *thr_state;
+    __syncthreads();
+    if (t == 0) { __threadfence(); ctl->thr = *thr_state; }
 }
 
 // masked mean of the NLL: kept = valid && (!do_select || prob < thr)
@@ -285,16 +392,22 @@ extern "C" int ss_ohem_ce_fwd(int dtype, const void* logits, int64_t sn, int64_t
     Strides s{sn, sc, sh, sw};
     SS_HIP(hipMemsetAsync(workspace, 0, 256 + 3 * OHEM_BINS * 4, stream));
     const int gb = nblk(npix, 4096);
-    SS_DISPATCH(dtype, hipLaunchKernelGGL((ce_prob_kernel<T>), dim3(gb), dim3(256), 0, stream, (const T*)logits, s, (const long long*)labels, prob, nll,
-                                          vkey, ctl, npix, H, W, C, (long long)ignore_index));
+    if (ce_channels_last(sn, sc, sh, sw, C, H, W)) {
+        const int pairs = dtype == SS_BF16 && C % 2 == 0 && sw % 2 == 0 && ((uintptr_t)logits & 3) == 0;
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((ce_prob_cl_kernel<T>), dim3(nblk(npix, 16384)), dim3(256), 0, stream, (const T*)logits, sw,
+                                              (const long long*)labels, prob, nll, vkey, ctl, npix, C, (long long)ignore_index, pairs));
+    } else {
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((ce_prob_kernel<T>), dim3(gb), dim3(256), 0, stream, (const T*)logits, s, (const long long*)labels, prob, nll,
+                                              vkey, ctl, npix, H, W, C, (long long)ignore_index));
+    }
     hipLaunchKernelGGL(ohem_plan_kernel, dim3(1), dim3(1), 0, stream, ctl, min_kept);
     for (int pass = 0; pass < 3; ++pass) {
         hipLaunchKernelGGL(ohem_hist_kernel, dim3(gb < 1024 ? gb : 1024), dim3(256), 0, stream, vkey, npix, ctl, hist + pass * OHEM_BINS, pass);
-        hipLaunchKernelGGL(ohem_scan_kernel, dim3(1), dim3(1), 0, stream, ctl, hist + pass * OHEM_BINS, pass);
+        hipLaunchKernelGGL(ohem_scan_kernel, dim3(1), dim3(256), 0, stream, ctl, hist + pass * OHEM_BINS, pass);
     }
     hipLaunchKernelGGL(ohem_chunk_count_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, vkey, npix, ctl, cntv, cnte);
     hipLaunchKernelGGL(ohem_locate_chunk_kernel, dim3(1), dim3(1024), 0, stream, ctl, cntv, cnte, (int)nchunks);
-    hipLaunchKernelGGL(ohem_threshold_kernel, dim3(1), dim3(1), 0, stream, ctl, vkey, prob, npix, thr_state);
+    hipLaunchKernelGGL(ohem_threshold_kernel, dim3(1), dim3(256), 0, stream, ctl, vkey, prob, npix, thr_state);
     const int rb = (int)(cdiv(npix, 1024) < CE_REDUCE_BLOCKS ? cdiv(npix, 1024) : CE_REDUCE_BLOCKS);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(rb), dim3(256), 0, stream, prob, nll, vkey, ctl, npix, psum, pcnt);
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, stream, ctl, psum, pcnt, rb, loss);
@@ -309,8 +422,15 @@ extern "C" int ss_ohem_ce_bwd(int dtype, const void* logits, int64_t sn, int64_t
     SS_CHECK(logits && labels && prob && ctl && gout && dlogits && B > 0 && C > 0 && H > 0 && W > 0, "ss_ohem_ce_bwd: bad arguments");
     const int64_t npix = (int64_t)B * H * W;
     Strides s{sn, sc, sh, sw}, so{on, oc, oh, ow};
-    SS_DISPATCH(dtype, hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(nblk(npix, 8192)), dim3(256), 0, stream, (const T*)logits, s, (const long long*)labels,
-                                          prob, (const OhemCtl*)ctl, gout, (T*)dlogits, so, npix, H, W, C, (long long)ignore_index));
+    if (ce_channels_last(sn, sc, sh, sw, C, H, W) && ce_channels_last(on, oc, oh, ow, C, H, W)) {
+        const int pairs = dtype == SS_BF16 && C % 2 == 0 && sw % 2 == 0 && ow % 2 == 0 && ((((uintptr_t)logits) | ((uintptr_t)dlogits)) & 3) == 0;
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((ce_bwd_cl_kernel<T>), dim3(nblk(npix, 16384)), dim3(256), 0, stream, (const T*)logits, sw,
+                                              (const long long*)labels, prob, (const OhemCtl*)ctl, gout, (T*)dlogits, ow, npix, C,
+                                              (long long)ignore_index, pairs));
+    } else {
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(nblk(npix, 8192)), dim3(256), 0, stream, (const T*)logits, s, (const long long*)labels,
+                                              prob, (const OhemCtl*)ctl, gout, (T*)dlogits, so, npix, H, W, C, (long long)ignore_index));
+    }
     SS_LAUNCH_CHECK();
     return 0;
 }

@@ -32,18 +32,20 @@ def test_ohem_ce_matches_reference_golden(golden_dir):
             assert np.float32(crit.threshold) == g[f'ohem.{name}.{call}.thr'], (name, call)
 
 
-def test_ohem_ce_strided_channels_last_and_bf16_vs_oracle():
+@pytest.mark.parametrize('C', [7, 6, 8, 2])
+def test_ohem_ce_strided_channels_last_and_bf16_vs_oracle(C):
+    """NHWC-strided logits (what the networks return): the channels-last kernels, scalar (odd C) and 4-byte-pair (even C, bf16) loads."""
     from oracle.losses import OhemCE
     from semseg_amd.loss import OhemCrossEntropyLoss
-    logits = det_input('l2.logits', (3, 7, 40, 24), -4, 4)
-    lab = det_labels('l2.lab', (3, 40, 24), 7, cell=4)
+    logits = det_input('l2.logits', (3, C, 40, 24), -4, 4)
+    lab = det_labels('l2.lab', (3, 40, 24), C, cell=4)
     for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
         lq = logits.to(dtype).float()
         ref_in = lq.clone().requires_grad_(True)
-        ref = OhemCE(2, 0.6, 0.3)(ref_in, lab)
+        ref = OhemCE(1, 0.6, 0.3)(ref_in, lab)
         ref.backward()
         cl = lq.to(dtype).cuda().permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).requires_grad_(True)   # NHWC strides
-        loss = OhemCrossEntropyLoss(2, 0.6, 0.3)(cl, lab.cuda())
+        loss = OhemCrossEntropyLoss(1, 0.6, 0.3)(cl, lab.cuda())
         loss.backward()
         assert rel(loss, ref) < tol and rel(cl.grad, ref_in.grad) < max(tol, 1e-4) * 4
 
