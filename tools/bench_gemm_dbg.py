@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from semseg_amd import ops
 NT = [(262144, 512, 512), (65536, 1280, 320), (262144, 2560, 512), (262144, 512, 2560)]
+if os.environ.get('SS_SHAPES'):
+    NT = [tuple(int(v) for v in t.split('x')) for t in os.environ['SS_SHAPES'].split(',')]
 def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
