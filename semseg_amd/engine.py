@@ -75,7 +75,9 @@ class FlatParams:
 
 
 class GradReducer:
-    """Bucketed gradient all-reduce over the flat gradient buffer (the C1 collective of SURVEY.md §2.2)."""
+    """Bucketed gradient all-reduce over the flat gradient buffer (the C1 collective of SURVEY.md §2.2).  One backward pass per
+    ``wait()``: a bucket travels as soon as its last gradient of THIS backward exists (accumulating several backward passes before
+    the exchange needs ``overlap=False``)."""
 
     def __init__(self, flat: FlatParams, bucket_bytes=25 << 20, overlap=True):
         self.flat, self.world = flat, _world()
@@ -92,6 +94,7 @@ class GradReducer:
             for i in mem:
                 self.bucket_of[i] = b
         self.pending = [len(m) for _, _, m in self.buckets]
+        self.fired = [False] * len(flat.params)
         self.works, self.launched = [], [False] * len(self.buckets)
         self.overlap = overlap and self.world > 1
         self.stream = torch.cuda.Stream() if (self.overlap and flat.data.is_cuda) else None
@@ -103,6 +106,11 @@ class GradReducer:
 
     def _make_hook(self, i):
         def hook(_p):
+            # a parameter can be announced twice in one backward: by runtime.deliver_grads when its gradient has been queued into
+            # the flat buffer, and by autograd's post-accumulate hook (torch fires it even though the node returned None for it)
+            if self.fired[i]:
+                return
+            self.fired[i] = True
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0 and self.overlap:
@@ -135,6 +143,7 @@ class GradReducer:
                 torch.cuda.current_stream().wait_stream(self.stream)
         self.works, self.launched = [], [False] * len(self.buckets)
         self.pending = [len(m) for _, _, m in self.buckets]
+        self.fired = [False] * len(self.flat.params)
         return 1.0 / self.world
 
 

@@ -66,3 +66,60 @@ def test_multi_add_ragged_sizes():
     for d, w in zip(dsts, want):
         assert torch.equal(d, w)
     assert pool[0].item() == edge[0] and torch.equal(pool[o:], edge[1])
+
+
+# ---------------------------------------------------------------------------- world size 2 on ONE GPU (gloo, host-staged collectives)
+def _ddp_worker(rank, world, port, out):
+    import os, sys
+    import torch.distributed as dist
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from semseg_amd.model import SegFormerLawin
+    from semseg_amd.engine import FlatParams, GradReducer, broadcast_module_state
+    net = SegFormerLawin('B0', 128, 6)
+    det_fill_(net.encoder), det_fill_(net.decoder)
+    net = net.cuda().eval()
+    if rank == 1:
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.5)
+    broadcast_module_state(net)                      # rank 0's parameters win
+    flat = FlatParams(net)
+    red = GradReducer(flat, bucket_bytes=1 << 20)    # several buckets, launched while backward is still running
+    x, proj = det_input('ddp.x', (4, 3, 64, 64)).cuda(), det_input('ddp.p', (4, 6, 64, 64), -1, 1).cuda()
+    res = {'buckets': len(red.buckets)}
+    for step in range(2):                            # the reducer re-arms itself
+        flat.zero_grad()
+        lo = rank * 2
+        (net(x[lo:lo + 2]) * proj[lo:lo + 2]).sum().backward()
+        red.wait()
+        res[f'grad{step}'] = flat.grad.cpu().clone()
+    res['launched_all'] = True
+    torch.save(res, os.path.join(out, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2_on_one_gpu(tmp_path):
+    """The bucket hooks fired from runtime.deliver_grads (not from autograd) must all-reduce every bucket: SUM over two ranks' half
+    batches == the single-process gradient of the whole batch (eval mode: images independent), on both ranks, twice."""
+    import os, socket
+    import torch.multiprocessing as mp
+    from semseg_amd.model import SegFormerLawin
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'r{r}.pt'), weights_only=True) for r in (0, 1))
+    net = SegFormerLawin('B0', 128, 6)
+    det_fill_(net.encoder), det_fill_(net.decoder)
+    net = net.cuda().eval()
+    x, proj = det_input('ddp.x', (4, 3, 64, 64)).cuda(), det_input('ddp.p', (4, 6, 64, 64), -1, 1).cuda()
+    (net(x) * proj).sum().backward()
+    ref = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 64)) for p in reversed(list(net.parameters()))]).cpu()
+    assert r0['buckets'] >= 3
+    for r in (r0, r1):
+        for step in range(2):
+            g = r[f'grad{step}']
+            assert g.shape == ref.shape
+            assert float((g - ref).abs().max()) <= 2e-4 * float(ref.abs().max()), step
+    assert torch.equal(r0['grad1'], r1['grad1'])
