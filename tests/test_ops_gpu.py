@@ -377,3 +377,22 @@ def test_droppath_keep_matches_torch_ops(ops, dtype):
         want = (kp + u).floor_().float() / kp
         got = ops.droppath_keep(u, kp)
         assert got.shape == (4096,) and torch.equal(got, want.reshape(-1))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('k,C,H,W,pt,pl,act', [(7, 96, 19, 70, 3, 3, 0), (5, 32, 9, 130, 2, 2, 2), (3, 64, 8, 64, 1, 1, 3), (7, 32, 5, 3, 3, 3, 1),
+                                                (5, 32, 12, 66, 1, 3, 0), (7, 40, 10, 20, 3, 3, 0)])
+def test_dwconvk_stride1_tiled_and_fallback(ops, dtype, k, C, H, W, pt, pl, act):
+    """depthwise k x k, stride 1: the LDS-tiled kernel (C % 32 == 0; ragged tiles, asymmetric padding, fused activation) and the
+    per-pixel fallback (C = 40) against F.conv2d on explicitly padded input."""
+    B = 2
+    x, w, b = rnd(B, C, H, W), rnd(C, 1, k, k, seed=1) / k, rnd(C, seed=2)
+    Ho, Wo = H + 2 * pt - k + 1 if pt * 2 >= k - 1 else H, W
+    Ho, Wo = H, W                                              # 'same' output size: bottom / right padding takes the rest
+    xp = F.pad(q(x, dtype), (pl, k - 1 - pl, pt, k - 1 - pt))
+    ref = F.conv2d(xp, w, b, groups=C)
+    ref = {0: ref, 1: F.gelu(ref), 2: F.relu(ref), 3: F.relu6(ref)}[act]
+    xn = dev(x.permute(0, 2, 3, 1).reshape(-1, C).contiguous(), dtype)
+    wt = dev(w.reshape(C, k * k).t().contiguous())
+    y = ops.dwconvk_fwd(xn, wt, dev(b), B, H, W, k, 1, pt, pl, Ho, Wo, act=act)
+    assert rel(y.view(B, Ho, Wo, C), ref.permute(0, 2, 3, 1)) < _tol(dtype)
