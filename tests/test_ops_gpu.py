@@ -396,3 +396,21 @@ def test_dwconvk_stride1_tiled_and_fallback(ops, dtype, k, C, H, W, pt, pl, act)
     wt = dev(w.reshape(C, k * k).t().contiguous())
     y = ops.dwconvk_fwd(xn, wt, dev(b), B, H, W, k, 1, pt, pl, Ho, Wo, act=act)
     assert rel(y.view(B, Ho, Wo, C), ref.permute(0, 2, 3, 1)) < _tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('k,C,H,W', [(7, 96, 19, 70), (5, 32, 9, 130), (3, 64, 8, 64), (7, 8, 5, 3), (7, 40, 33, 20)])
+def test_dwconvk_weight_gradient(ops, dtype, k, C, H, W):
+    """dW, db of a depthwise k x k (stride 1, padding k//2) against torch autograd; strips of several tiles, ragged edges; bitwise
+    reproducible."""
+    B = 3
+    x, g = rnd(B, C, H, W), rnd(B, C, H, W, seed=1)
+    w = torch.zeros(C, 1, k, k, requires_grad=True)
+    bias = torch.zeros(C, requires_grad=True)
+    F.conv2d(q(x, dtype), w, bias, padding=k // 2, groups=C).backward(q(g, dtype))
+    xn = dev(x.permute(0, 2, 3, 1).reshape(-1, C).contiguous(), dtype)
+    gn = dev(g.permute(0, 2, 3, 1).reshape(-1, C).contiguous(), dtype)
+    out = ops.dwconvk_wgrad(gn, xn, B, H, W, k)
+    assert out.shape == (k * k + 1, C)
+    assert rel(out[:k * k].t().reshape(C, 1, k, k), w.grad) < 1e-4 and rel(out[k * k], bias.grad) < 1e-4
+    assert torch.equal(out, ops.dwconvk_wgrad(gn, xn, B, H, W, k))
