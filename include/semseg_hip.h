@@ -33,7 +33,9 @@ int ss_version(void);
  * conv as im2col GEMM); modules/lawin.py:10,14 (MLP.proj), :49-53,72-80 (g/theta/phi/conv_out), :100 (ConvModule.conv),
  * :137 (linear_pred).
  * C[M,N] = act(A[M,K] . B[N,K]^T + bias[N]) * rowscale[row / rows_per_scale] + res[M,N];  act: 0 none, 1 GELU(erf), 2 ReLU, 3 ReLU6,
- * 4 h-sigmoid, 5 sigmoid (the conv-BN-act blocks of modules/topformer.py with BN folded into B and bias in eval mode).
+ * 4 h-sigmoid, 5 sigmoid (the conv-BN-act blocks of modules/topformer.py with BN folded into B and bias in eval mode);
+ * 6: C = (A . B^T + bias) * rowscale * GELU'(res) -- the gradient through the GELU between ConvNeXt's pointwise convolutions
+ * (modules/convnext.py:43-45) taken in the epilogue of the data-gradient GEMM, res = the saved pre-activation.
  * out_f32 != 0 stores C (and reads res) as fp32 even for bf16 operands. */
 int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldr,

@@ -100,8 +100,7 @@ class _BlockFn(_ParamFn):
             G['gamma'] = ops.rowdot_f32(gw, P['pw_conv2.weight'].detach().contiguous()) + cs * P['pw_conv2.bias'].detach()
         else:
             G['pw_conv2.weight'], G['pw_conv2.bias'] = gw, cs
-        da = ops.gemm_nt(g, w_bwd(S['w2s'], T))
-        dz1 = ops.gelu_bwd(da, S['z1'])
+        dz1 = ops.gemm_nt(g, w_bwd(S['w2s'], T), res=S['z1'], act=ops.GELU_GRAD)    # (g W2) * GELU'(z1) in the GEMM epilogue
         G['pw_conv1.weight'], G['pw_conv1.bias'] = linear_grads(dz1, S['n'])
         dn = ops.gemm_nt(dz1, w_bwd(P['pw_conv1.weight'], T))
         dd, dgb = ops.layernorm_bwd(dn, S['d'], S['m'], S['r'], P['norm.weight'])

@@ -188,9 +188,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 float v = acc[a][b][r];
                 if (!TRANS) {
                     v += bv;
-                    v = apply_act(v, p.act);
-                    if (p.rowscale) v *= p.rowscale[row / p.rows_per_scale];
-                    if (R) v += to_f(R[row * p.ldr + col]);
+                    if (p.act == 6) {                     // gradient through a GELU: times GELU'(res), res = the pre-activation
+                        if (p.rowscale) v *= p.rowscale[row / p.rows_per_scale];
+                        v *= gelu_erf_grad(to_f(R[row * p.ldr + col]));
+                    } else {
+                        v = apply_act(v, p.act);
+                        if (p.rowscale) v *= p.rowscale[row / p.rows_per_scale];
+                        if (R) v += to_f(R[row * p.ldr + col]);
+                    }
                 }
                 C[row * p.ldc + col] = from_f<TC>(v);
             }
@@ -296,6 +301,7 @@ extern "C" int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, co
                           const float* rowscale, int64_t rows_per_scale, int act, hipStream_t stream) {
     SS_CHECK(A && B && C, "ss_gemm_nt: null operand");
     SS_CHECK(M > 0 && N > 0 && K > 0 && N < (1 << 30), "ss_gemm_nt: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+    SS_CHECK(act >= 0 && act <= 6 && (act != 6 || res), "ss_gemm_nt: act must be 0..6, and 6 (times GELU'(res)) needs res");
     SS_CHECK(lda >= K && ldb >= K && ldc >= N, "ss_gemm_nt: leading dimension smaller than the row");
     SS_CHECK(!res || ldr >= N, "ss_gemm_nt: bad ldr");
     SS_CHECK(!rowscale || rows_per_scale > 0, "ss_gemm_nt: rows_per_scale must be > 0");

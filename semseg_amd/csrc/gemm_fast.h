@@ -54,8 +54,8 @@ __device__ __forceinline__ void nt_epilogue_cells(floatx16 (&acc)[TA][TB], const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[a][b][4 * g + e] + bv[e];
-                    v = apply_act(v, ACT);
-                    v = RES ? v * rs + (float)rv[e] : v * rs;
+                    if (ACT == 6) v = v * rs * gelu_erf_grad((float)rv[e]);       // RES is true: the image holds the pre-activation
+                    else { v = apply_act(v, ACT); v = RES ? v * rs + (float)rv[e] : v * rs; }
                     o[e] = (bf16)v;
                 }
                 *cell = o;
@@ -74,6 +74,7 @@ __device__ __forceinline__ void nt_epilogue_dispatch(floatx16 (&acc)[TA][TB], co
             case 3: SS_EPI(3, true); break;
             case 4: SS_EPI(4, true); break;
             case 5: SS_EPI(5, true); break;
+            case 6: SS_EPI(6, true); break;
             default: SS_EPI(0, true); break;
         }
     } else {

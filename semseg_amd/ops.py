@@ -820,6 +820,7 @@ def bilinear_add(x, y, B, hi, wi, ho, wo):
 
 # ---------------------------------------------------------------------------------- TopFormer RefinerHead (inference)
 SIGMOID = 5
+GELU_GRAD = 6            # ss_gemm_nt epilogue: times GELU'(res)
 
 
 def image_moments(x, images, pre_act=0):

@@ -414,3 +414,17 @@ def test_dwconvk_weight_gradient(ops, dtype, k, C, H, W):
     assert out.shape == (k * k + 1, C)
     assert rel(out[:k * k].t().reshape(C, 1, k, k), w.grad) < 1e-4 and rel(out[k * k], bias.grad) < 1e-4
     assert torch.equal(out, ops.dwconvk_wgrad(gn, xn, B, H, W, k))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N,K', [(1000, 384, 96), (70000, 768, 192), (513, 96, 384)])
+def test_gemm_nt_gelu_gradient_epilogue(ops, dtype, M, N, K):
+    """act 6: (A . B^T) * GELU'(res), the GELU backward of modules/convnext.py:43-45 inside the data-gradient GEMM."""
+    a, b, z = rnd(M, K), rnd(N, K, seed=1) / math.sqrt(K), rnd(M, N, seed=2) * 2
+    zr = q(z, dtype).requires_grad_(True)
+    F.gelu(zr).backward(torch.ones_like(zr))
+    ref = (q(a, dtype) @ q(b, dtype).t()) * zr.grad
+    out = ops.gemm_nt(dev(a, dtype), dev(b, dtype), res=dev(z, dtype), act=ops.GELU_GRAD)
+    assert rel(out, ref) < _tol(dtype)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(dev(a, dtype), dev(b, dtype), act=ops.GELU_GRAD)
