@@ -423,7 +423,9 @@ extern "C" int ss_bcast_rows(int dtype, const void* v, void* y, int64_t ldy, int
 // The per-step casts / transposes / conv-weight packings of the fp32 master weights (ss_cast, ss_transpose_cast,
 // ss_pack_conv_weight: ~280 launches of ~5 us each per MiT-B2 + Lawin step) replayed from a table that lives in device memory:
 // entry e = { src, dst, n_out, kind | dst_dtype << 8 | reverse << 16, a, b, c, first_block } (8 x int64), element formulas
-// identical to the single-tensor kernels above.  A block owns 1024 consecutive output elements of one entry.
+// identical to the single-tensor kernels above.  A block owns 1024 consecutive output elements of one entry, except for
+// kind 1, where it owns one 32 x 32 tile (ceil(R / 32) * ceil(Cc / 32) blocks, row tiles fastest) and goes through LDS so
+// that both the fp32 reads and the stores are contiguous.
 //   kind 0 cast            dst[i] = src[i]
 //   kind 1 transpose_cast  src [a = R][b = Cc] -> dst [Cc][R]
 //   kind 2 pack (wp)       src [a = O][b = I][k][k] -> dst [O][Kp], c = k | Kp << 32
@@ -433,7 +435,7 @@ __device__ __forceinline__ void prep_block(const int64_t* __restrict__ ent, int6
     const float* __restrict__ src = (const float*)ent[0];
     TO* __restrict__ dst = (TO*)ent[1];
     const int64_t n = ent[2];
-    const int kind = (int)(ent[3] & 0xff), reverse = (int)((ent[3] >> 16) & 1);
+    const int kind = (int)(ent[3] & 0xff);                 // 0, 2 or 3 here: kind 1 is tiled in the kernel below
     const int a = (int)ent[4], b = (int)ent[5], k = (int)(ent[6] & 0xffffffff), Kp = (int)(ent[6] >> 32);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -441,7 +443,6 @@ __device__ __forceinline__ void prep_block(const int64_t* __restrict__ ent, int6
         if (i >= n) break;
         float v;
         if (kind == 0) v = src[i];
-        else if (kind == 1) { const int c = (int)(i / a), r = (int)(i % a); v = src[(int64_t)r * b + (reverse ? b - 1 - c : c)]; }
         else {
             int o, kc;
             if (kind == 2) { o = (int)(i / Kp); kc = (int)(i % Kp); } else { kc = (int)(i / a); o = (int)(i % a); }
@@ -459,6 +460,28 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const int64_t* _
         if (table[(int64_t)mid * 8 + 7] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const int64_t* ent = table + (int64_t)lo * 8;
+    if ((ent[3] & 0xff) == 1) {
+        __shared__ float tile[32][33];
+        const int R = (int)ent[4], Cc = (int)ent[5], reverse = (int)((ent[3] >> 16) & 1), bf = ((ent[3] >> 8) & 0xff) == SS_BF16;
+        const int t = (int)((int64_t)blockIdx.x - ent[7]), tr = (R + 31) >> 5;
+        const int r0 = (t % tr) * 32, c0 = (t / tr) * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        const float* __restrict__ src = (const float*)ent[0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                       // tile[r][c] <- src[r0 + r][column of output row c0 + c]
+            const int r = r0 + ty + 8 * j, c = c0 + tx;
+            if (r < R && c < Cc) tile[ty + 8 * j][tx] = src[(int64_t)r * Cc + (reverse ? Cc - 1 - c : c)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + ty + 8 * j, r = r0 + tx;
+            if (r < R && c < Cc) {
+                const float v = tile[tx][ty + 8 * j];
+                if (bf) ((bf16*)ent[1])[(int64_t)c * R + r] = from_f<bf16>(v); else ((float*)ent[1])[(int64_t)c * R + r] = v;
+            }
+        }
+        return;
+    }
     const int64_t base = ((int64_t)blockIdx.x - ent[7]) * 1024;
     if (((ent[3] >> 8) & 0xff) == SS_BF16) prep_block<bf16>(ent, base); else prep_block<float>(ent, base);
 }

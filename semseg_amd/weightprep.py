@@ -50,7 +50,7 @@ def _refresh(st, device):
             n_out = e.out.numel()
             code = kind[0] | (ops._DT[e.out.dtype] << 8) | (kind[1] << 16)
             rows.append([e.src.data_ptr(), e.out.data_ptr(), n_out, code, a, b, c, blocks])
-            blocks += (n_out + 1023) // 1024
+            blocks += ((a + 31) // 32) * ((b + 31) // 32) if kind[0] == 1 else (n_out + 1023) // 1024
         st.table = torch.tensor(rows, dtype=torch.int64).to(device)
         st.table_n, st.blocks = n, blocks
     check(lib().ss_weight_prep_batch(st.table.data_ptr(), n, st.blocks, torch.cuda.current_stream(device).cuda_stream))
