@@ -36,6 +36,9 @@ def parse():
                     help="mit_lawin = BASELINE configs[1] (the headline); dnet = configs[2] per-GPU step (DNet-T, embed 256, batch 8, Dice loss)")
     ap.add_argument('--variant', default='B2')
     ap.add_argument('--head', default='simple', choices=['simple', 'refiner'], help='TopFormer head (configs[3]; predict.py uses refiner)')
+    ap.add_argument('--output', default='logits', choices=['logits', 'class_map', 'class_map_unfused'],
+                    help='topformer: what a step hands over -- full-size logits (the model forward), the uint8 class map of '
+                         'predict.py (fused resize + arg-max), or forward followed by the separate class-map kernel')
     ap.add_argument('--embed', type=int, default=512)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--size', type=int, default=1024)
@@ -251,17 +254,19 @@ def topformer_inference(a, world, rank, dev):
     batch = a.batch if a.batch != 16 else 4
     net = det_fill_(TopFormerModel(6, 'B', head_cfg=frozenset({'alias': a.head}.items()))).to(dev).eval()
     x, _ = synthetic_batch(batch, size, rank, dev)
+    from semseg_amd import postproc
+    step = {'logits': net, 'class_map': net.predict_class_map, 'class_map_unfused': lambda t: postproc.class_map(net(t))}[a.output]
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
     for _ in range(a.warmup):
-        net(x)
+        step(x)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = net(x)
+        out = step(x)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -269,14 +274,14 @@ def topformer_inference(a, world, rank, dev):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     _lib.TRACE = []
-    net(x)
+    step(x)
     trace, _lib.TRACE = _lib.TRACE, None
     if rank == 0:
         table = kernel_table(trace)
         res = {'metric': 'inference images/sec @2048x2048 (TopFormer-B)', 'value': batch * world * a.steps / dt, 'unit': 'images/s', 'n_gpus': world,
                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-               'config': {'workload': f'configs[3]: TopFormer-B + {a.head} head inference, {size}x{size}', 'per_gpu_batch': batch,
+               'config': {'workload': f'configs[3]: TopFormer-B + {a.head} head inference, {size}x{size}, output {a.output}', 'per_gpu_batch': batch,
                           'global_batch': batch * world, 'parallelism': f'replicas x{world}'},
                'roofline': roofline_from_table(table)}
         if a.table:

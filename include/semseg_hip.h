@@ -204,6 +204,23 @@ int ss_dice_bwd(int dtype, const int64_t* labels, const float* coef_hit, const f
 int ss_confusion_update(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,
                         int64_t* cm, int B, int C, int H, int W, hipStream_t stream);
 
+/* ---- Next rows of SURVEY.md 8(f): the steps right after the forward in predict.py and scripts/evaluate.py.
+ * ss_class_map_u8: PredictionWriter.write_on_batch_end (helper/callbacks.py:52-54), prediction.softmax(1).argmax(1): softmax is
+ *   increasing in the logit, so the arg-max is taken on the logits (first maximum wins, a pixel holding a NaN -> 0, what softmax +
+ *   torch.argmax give); out = uint8 [B][H][W], dense, 4-byte aligned -- one byte per pixel to the host instead of an int64.
+ * ss_bilinear_class_map_u8: the same on logits still at the head's resolution, x = [B*hi*wi rows, C of ldx columns] channels-last:
+ *   out[b][oy][ox] = arg-max over c of the value ss_bilinear_fwd would have stored at (oy, ox) (same taps and roundings), so
+ *   core/models.py:105-115's full-size logits are never written.  out = uint8 [B][ho][wo].
+ * ss_confusion_labels_u8: scripts/evaluate.py:130-135, sklearn confusion_matrix(y_true, y_pred, labels) of two class-map rasters
+ *   over the pixels `valid` marks (null = all); lut = int32 [256] on the device, raster value -> index in `labels` or -1 (pixel
+ *   dropped, as sklearn does for a value that is not listed); cm = int64 [C][C] (rows = truth), accumulated in place, exact. */
+int ss_class_map_u8(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, uint8_t* out, int B, int C, int H,
+                    int W, hipStream_t stream);
+int ss_bilinear_class_map_u8(int dtype, const void* x, int64_t ldx, uint8_t* out, int B, int hi, int wi, int ho, int wo, int C,
+                             hipStream_t stream);
+int ss_confusion_labels_u8(const uint8_t* truth, const uint8_t* pred, const uint8_t* valid, const int* lut, int64_t* cm, int64_t n, int C,
+                           hipStream_t stream);
+
 /* ---- core/decoder.py:49-59 tail on channels-last maps.  x = LawinHead output [B,H4,W4,2oc].  The host runs two GEMMs on x:
  * z9 [rows, ld9 >= 9*oc] = x . Wd (ConvTranspose2d k3 s4 weight as [(o,dy,dx)][c], modules/blocks.py:224-234) and bs [rows, oc] =
  * conv1x1(x) + b (feature_reducer, core/decoder.py:38-47; the 1x1 conv commutes with the nearest up-sampling of :52-58).

@@ -356,6 +356,61 @@ __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ lo
     for (int i = threadIdx.x; i < C * C; i += blockDim.x) if (bins[i]) atomicAdd(&cm[i], (unsigned long long)bins[i]);
 }
 
+// ------------------------------------------------------------------ prediction writer / evaluation script
+// helper/callbacks.py:52-54: prediction.softmax(dim=1).argmax(dim=1) -> class map.  softmax is increasing in the logit, so the
+// arg-max is taken on the logits themselves; the first maximum wins (torch.argmax); a pixel that holds a NaN gets class 0
+// (softmax turns the whole pixel into NaN and torch.argmax returns the first of them).  One byte per pixel instead of the
+// reference's int64.  A thread owns 4 consecutive pixels (one 4-byte store).
+// A thread owns ONE pixel (lanes walk the image in storage order, so channels-last and NCHW logits both load coalesced; VEC:
+// the channels of a pixel are contiguous and 16-byte aligned, read as whole 16-byte chunks); the classes of 4 neighbouring
+// lanes are packed into one 4-byte store.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void class_map_kernel(const T* __restrict__ logits, Strides s, unsigned char* __restrict__ out, int64_t npix,
+                                                        int H, int W, int C) {
+    constexpr int PER = 16 / (int)sizeof(T);
+    typedef T VT __attribute__((ext_vector_type(PER)));
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < npix; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        const T* p = logits + pix_off(i < npix ? i : npix - 1, H, W, s);
+        float best = 0.f; int arg = 0; bool nan = false;
+        if (VEC) {
+            for (int c0 = 0; c0 < C; c0 += PER) {
+                const VT v8 = *(const VT*)(p + c0);
+#pragma unroll
+                for (int e = 0; e < PER; ++e) {
+                    const float v = to_f(v8[e]);
+                    if (c0 + e < C) { nan |= v != v; if (c0 + e == 0 || v > best) { best = v; arg = c0 + e; } }
+                }
+            }
+        } else {
+            for (int c = 0; c < C; ++c) { const float v = to_f(p[c * s.c]); nan |= v != v; if (c == 0 || v > best) { best = v; arg = c; } }
+        }
+        const unsigned mine = nan ? 0u : (unsigned)arg;
+        const unsigned packed = mine | (__shfl_down(mine, 1) << 8) | (__shfl_down(mine, 2) << 16) | (__shfl_down(mine, 3) << 24);
+        if (base + blockDim.x <= npix) { if ((threadIdx.x & 3) == 0) *(unsigned*)(out + i) = packed; }
+        else if (i < npix) out[i] = (unsigned char)mine;
+    }
+}
+
+// scripts/evaluate.py:130-135: sklearn confusion_matrix(y_true, y_pred, labels) of two class-map rasters, restricted to the
+// pixels `valid` marks (null = all).  lut[256]: raster value -> row / column index, or -1 for a value that is not among
+// `labels` (sklearn drops a pixel whose truth or prediction is not listed).  cm: int64 [C][C], accumulated in place.
+__global__ __launch_bounds__(256) void confusion_labels_kernel(const unsigned char* __restrict__ truth, const unsigned char* __restrict__ pred,
+        const unsigned char* __restrict__ valid, const int* __restrict__ lut, unsigned long long* __restrict__ cm, int64_t n, int C) {
+    extern __shared__ unsigned bins[];
+    __shared__ int slut[256];
+    slut[threadIdx.x] = lut[threadIdx.x];
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) bins[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (valid && !valid[i]) continue;
+        const int t = slut[truth[i]], p = slut[pred[i]];
+        if (t >= 0 && p >= 0) atomicAdd(&bins[t * C + p], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) if (bins[i]) atomicAdd(&cm[i], (unsigned long long)bins[i]);
+}
+
 // ------------------------------------------------------------------ host entry points
 static inline int nblk(int64_t n, int cap) { int64_t b = cdiv(n, 256); return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
 #define CE_REDUCE_BLOCKS 1024
@@ -468,6 +523,32 @@ extern "C" int ss_confusion_update(int dtype, const void* logits, int64_t sn, in
     Strides s{sn, sc, sh, sw};
     SS_DISPATCH(dtype, hipLaunchKernelGGL((confusion_kernel<T>), dim3(nblk(npix, 2048)), dim3(256), (size_t)C * C * sizeof(unsigned), stream,
                                           (const T*)logits, s, (const long long*)labels, (unsigned long long*)cm, npix, H, W, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// out: uint8 [B][H][W] (dense, 4-byte aligned)
+extern "C" int ss_class_map_u8(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, uint8_t* out, int B, int C,
+                               int H, int W, hipStream_t stream) {
+    SS_CHECK(logits && out && B > 0 && C > 0 && C <= 256 && H > 0 && W > 0, "ss_class_map_u8: bad arguments (1 <= C <= 256)");
+    SS_CHECK(((uintptr_t)out & 3) == 0, "ss_class_map_u8: out must be 4-byte aligned");
+    const int64_t npix = (int64_t)B * H * W;
+    Strides s{sn, sc, sh, sw};
+    const int64_t esz = dtype == SS_BF16 ? 2 : 4, per = 16 / esz;
+    const bool vec = sc == 1 && aligned16(logits) && ((sn | sh | sw) * esz) % 16 == 0 && sw >= (C + per - 1) / per * per;
+    dim3 grid(nblk(npix, 16384));
+    if (vec) SS_DISPATCH(dtype, hipLaunchKernelGGL((class_map_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)logits, s, out, npix, H, W, C));
+    else SS_DISPATCH(dtype, hipLaunchKernelGGL((class_map_kernel<T, false>), grid, dim3(256), 0, stream, (const T*)logits, s, out, npix, H, W, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// truth, pred, valid (or null): uint8 [n]; lut: int32 [256] on the device; cm: int64 [C][C], accumulated in place
+extern "C" int ss_confusion_labels_u8(const uint8_t* truth, const uint8_t* pred, const uint8_t* valid, const int* lut, int64_t* cm, int64_t n,
+                                      int C, hipStream_t stream) {
+    SS_CHECK(truth && pred && lut && cm && n > 0 && C > 0 && C <= 100, "ss_confusion_labels_u8: bad arguments (1 <= C <= 100)");
+    hipLaunchKernelGGL(confusion_labels_kernel, dim3(nblk(n, 2048)), dim3(256), (size_t)C * C * sizeof(unsigned), stream, truth, pred, valid, lut,
+                       (unsigned long long*)cm, n, C);
     SS_LAUNCH_CHECK();
     return 0;
 }

@@ -140,6 +140,13 @@ __device__ __forceinline__ LinTap lin_tap(int o, float scale, int in) {
     return t;
 }
 
+// One interpolated value, with the roundings spelled out (explicit fma) so that every kernel below that interpolates -- the
+// resize kernels and the fused resize + arg-max of the prediction writer -- produces the same bits from the same taps.
+__device__ __forceinline__ float bilerp(const LinTap& ty, const LinTap& tx, float a, float b, float c, float d) {
+    const float top = fmaf(tx.l1, b, tx.l0 * a), bot = fmaf(tx.l1, d, tx.l0 * c);
+    return fmaf(ty.l1, bot, ty.l0 * top);
+}
+
 // grid: (B*ho output rows, blocks over the wo * chunks items of a row); the vertical tap is uniform per workgroup
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
@@ -157,11 +164,10 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
     if (VEC) {
         F8 a = load8(r0 + tx.i0 * ldx), bq = load8(r0 + tx.i1 * ldx), cq = load8(r1 + tx.i0 * ldx), d = load8(r1 + tx.i1 * ldx), o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.v[e] = ty.l0 * (tx.l0 * a.v[e] + tx.l1 * bq.v[e]) + ty.l1 * (tx.l0 * cq.v[e] + tx.l1 * d.v[e]);
+        for (int e = 0; e < 8; ++e) o.v[e] = bilerp(ty, tx, a.v[e], bq.v[e], cq.v[e], d.v[e]);
         store8(dst, o);
     } else {
-        float o = ty.l0 * (tx.l0 * to_f(r0[tx.i0 * ldx]) + tx.l1 * to_f(r0[tx.i1 * ldx])) +
-                  ty.l1 * (tx.l0 * to_f(r1[tx.i0 * ldx]) + tx.l1 * to_f(r1[tx.i1 * ldx]));
+        float o = bilerp(ty, tx, to_f(r0[tx.i0 * ldx]), to_f(r0[tx.i1 * ldx]), to_f(r1[tx.i0 * ldx]), to_f(r1[tx.i1 * ldx]));
         dst[0] = from_f<T>(o);
     }
 }
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_narrow_kernel(const T* __res
         const T* r1 = x + (((int64_t)b * hi + ty.i1) * wi) * ldx;
         const T *p00 = r0 + tx.i0 * ldx, *p01 = r0 + tx.i1 * ldx, *p10 = r1 + tx.i0 * ldx, *p11 = r1 + tx.i1 * ldx;
         for (int c = 0; c < C; ++c) {
-            const float o = ty.l0 * (tx.l0 * to_f(p00[c]) + tx.l1 * to_f(p01[c])) + ty.l1 * (tx.l0 * to_f(p10[c]) + tx.l1 * to_f(p11[c]));
+            const float o = bilerp(ty, tx, to_f(p00[c]), to_f(p01[c]), to_f(p10[c]), to_f(p11[c]));
             img[threadIdx.x * C + c] = from_f<T>(o);
         }
     }
@@ -194,6 +200,42 @@ __global__ __launch_bounds__(256) void bilinear_fwd_narrow_kernel(const T* __res
     } else {
         for (unsigned i = threadIdx.x; i < npx * C; i += 256u) dst[i] = img[i];
     }
+}
+
+// Prediction writer (helper/callbacks.py:52-54) on logits that are still at the head's resolution: class map of the resized
+// logits without ever writing them.  out[b, oy, ox] = first arg-max over c of the value ss_bilinear_fwd would have stored
+// (same taps, same roundings, rounded to T), a pixel holding a NaN -> 0 (see class_map_kernel in loss.hip for the rule).
+// A thread owns one output pixel (VEC: the channels of a tap are one 16-byte load), 4 neighbouring lanes share a 4-byte store.
+// grid: (B*ho rows, blocks of 256 px)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void bilinear_class_map_kernel(const T* __restrict__ x, int64_t ldx, unsigned char* __restrict__ out,
+        int hi, int wi, int ho, int wo, int C) {
+    const unsigned row = blockIdx.x, b = row / (unsigned)ho, oy = row - b * ho;
+    const unsigned ox0 = blockIdx.y * 256u, oxr = ox0 + threadIdx.x, ox = min(oxr, (unsigned)wo - 1);
+    const LinTap ty = lin_tap((int)oy, (float)hi / ho, hi), tx = lin_tap((int)ox, (float)wi / wo, wi);
+    const T* r0 = x + (((int64_t)b * hi + ty.i0) * wi) * ldx;
+    const T* r1 = x + (((int64_t)b * hi + ty.i1) * wi) * ldx;
+    const T *p00 = r0 + tx.i0 * ldx, *p01 = r0 + tx.i1 * ldx, *p10 = r1 + tx.i0 * ldx, *p11 = r1 + tx.i1 * ldx;
+    float best = 0.f; int arg = 0; bool nan = false;
+    if (VEC) {                                               // bf16, C <= 8, 16-byte aligned rows
+        const F8 a = load8(p00), bq = load8(p01), cq = load8(p10), d = load8(p11);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float v = to_f(from_f<T>(bilerp(ty, tx, a.v[c], bq.v[c], cq.v[c], d.v[c])));
+            if (c < C) { nan |= v != v; if (c == 0 || v > best) { best = v; arg = c; } }
+        }
+    } else {
+        for (int c = 0; c < C; ++c) {
+            const float v = to_f(from_f<T>(bilerp(ty, tx, to_f(p00[c]), to_f(p01[c]), to_f(p10[c]), to_f(p11[c]))));
+            nan |= v != v;
+            if (c == 0 || v > best) { best = v; arg = c; }
+        }
+    }
+    const unsigned mine = nan ? 0u : (unsigned)arg;
+    const unsigned packed = mine | (__shfl_down(mine, 1) << 8) | (__shfl_down(mine, 2) << 16) | (__shfl_down(mine, 3) << 24);
+    unsigned char* dst = out + (int64_t)row * wo + oxr;
+    if ((wo & 3) == 0 && ((uintptr_t)out & 3) == 0) { if ((threadIdx.x & 3) == 0 && oxr < (unsigned)wo) *(unsigned*)dst = packed; }
+    else if (oxr < (unsigned)wo) *dst = (unsigned char)mine;
 }
 
 // gather-form backward: dx[b,iy,ix,:] = sum over the output pixels whose taps touch (iy,ix).
@@ -266,6 +308,19 @@ extern "C" int ss_bilinear_fwd(int dtype, const void* x, int64_t ldx, void* y, i
     SS_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int ss_bilinear_class_map_u8(int dtype, const void* x, int64_t ldx, uint8_t* out, int B, int hi, int wi, int ho, int wo, int C,
+                                        hipStream_t stream) {
+    SS_CHECK(x && out && B > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && C > 0 && C <= 256 && ldx >= C,
+             "ss_bilinear_class_map_u8: bad arguments (1 <= C <= 256, ldx >= C)");
+    SS_CHECK((int64_t)B * ho < (1LL << 31) && cdiv(wo, 256) < 65536, "ss_bilinear_class_map_u8: image too large");
+    dim3 grid((unsigned)(B * ho), (unsigned)cdiv(wo, 256));
+    if (dtype == SS_BF16 && C <= 8 && ldx % 8 == 0 && aligned16(x))
+        hipLaunchKernelGGL((bilinear_class_map_kernel<bf16, true>), grid, dim3(256), 0, stream, (const bf16*)x, ldx, out, hi, wi, ho, wo, C);
+    else SS_DISPATCH(dtype, hipLaunchKernelGGL((bilinear_class_map_kernel<T, false>), grid, dim3(256), 0, stream, (const T*)x, ldx, out, hi, wi, ho, wo, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ss_bilinear_bwd(int dtype, const void* dy, int64_t ldy, void* dx, int64_t ldx, int B, int hi, int wi, int ho, int wo, int C,
                                int accumulate, hipStream_t stream) {
     SS_CHECK(dy && dx && B > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && C > 0 && ldx >= C && ldy >= C, "ss_bilinear_bwd: bad arguments");

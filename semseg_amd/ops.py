@@ -616,6 +616,46 @@ def confusion_update(logits, labels, cm):
     return cm
 
 
+def class_map(prediction):
+    """[B, C, H, W] logits (any strides) -> uint8 [B, H, W]: prediction.softmax(1).argmax(1) of helper/callbacks.py:52-54."""
+    dev = _dev(prediction)
+    (B, C, H, W), (sn, sc, sh, sw) = _nchw(prediction, 'prediction')
+    if C > 256:
+        raise ValueError('class_map: at most 256 classes fit a uint8 class map')
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    check(lib().ss_class_map_u8(dt(prediction), _p(prediction), sn, sc, sh, sw, _p(out), B, C, H, W, _stream()))
+    return out
+
+
+def bilinear_class_map(x, B, hi, wi, ho, wo, C):
+    """x [B*hi*wi, >= C] channels-last logits -> uint8 [B, ho, wo] = class_map(bilinear_fwd(x)[..., :C]) without the resized logits."""
+    dev = _dev(x)
+    rows, cols, ld = _mat(x, 'x')
+    if rows != B * hi * wi or C > cols or C > 256:
+        raise ValueError(f'bilinear_class_map: x is [{rows}, {cols}], expected [{B * hi * wi}, >= {C}] with C <= 256')
+    out = torch.empty((B, ho, wo), dtype=torch.uint8, device=dev)
+    check(lib().ss_bilinear_class_map_u8(dt(x), _p(x), ld, _p(out), B, hi, wi, ho, wo, C, _stream()))
+    return out
+
+
+def confusion_labels(truth, pred, lut, C, valid=None, cm=None):
+    """uint8 class maps of one shape -> int64 [C, C] += counts over (lut[truth], lut[pred]) where both are >= 0 and valid != 0."""
+    dev = _dev(truth)
+    for name, t in (('truth', truth), ('pred', pred)) + ((('valid', valid),) if valid is not None else ()):
+        if t.dtype != torch.uint8 or not t.is_contiguous() or t.shape != truth.shape or t.device != dev:
+            raise ValueError(f'confusion_labels: {name} must be a contiguous uint8 tensor shaped like truth, on its device')
+    if lut.dtype != torch.int32 or lut.numel() != 256 or not lut.is_contiguous() or lut.device != dev:
+        raise ValueError('confusion_labels: lut must be a contiguous int32 [256] tensor on the device')
+    if cm is None:
+        cm = torch.zeros((C, C), dtype=torch.int64, device=dev)
+    elif cm.dtype != torch.int64 or cm.shape != (C, C) or not cm.is_contiguous():
+        raise ValueError('confusion_labels: cm must be contiguous int64 [C, C]')
+    if truth.numel():
+        check(lib().ss_confusion_labels_u8(_p(truth), _p(pred), _p(valid) if valid is not None else None, _p(lut), _p(cm), truth.numel(), C,
+                                           _stream()))
+    return cm
+
+
 def colsum_any(x):
     """[rows, C] -> [C] fp32 column sums for any C (narrow tensors use the scalar kernel)."""
     rows, C, ld = _mat(x, 'x')

@@ -416,27 +416,42 @@ class TopFormerModel(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         b, c, H, W = x.shape
         with torch.no_grad():
-            plan = self.backbone._plan_for(self, x)
-            feats = list(self.backbone._run(x, plan).values())
-            h4, w4 = max(f[1] for f in feats), max(f[2] for f in feats)         # UniRes target: the largest map (modules/heads.py:78-82)
-            if isinstance(self.head, RefinerHead):
-                logits4 = self._refiner(plan, feats, b, h4, w4)
-            else:
-                if self.fusion == 'sum':
-                    if (feats[0][1], feats[0][2]) != (h4, w4):
-                        raise ValueError('TopFormerModel: the first stage must be the finest map')
-                    acc = feats[0][0]
-                    for t, h, w in feats[1:]:
-                        ops.bilinear_add(t, acc, b, h, w, h4, w4)
-                else:                                                           # Concat(dim=1): stage g fills channel slice g
-                    C = feats[0][0].shape[1]
-                    acc = torch.empty((b * h4 * w4, C * len(feats)), dtype=plan.T, device=x.device)
-                    for g, (t, h, w) in enumerate(feats):
-                        ops.bilinear_fwd(t, b, h, w, h4, w4, out=acc[:, g * C:(g + 1) * C])
-                y = ops.gemm_nt(acc, plan.head[0], bias=plan.head[1], act=RELU6)
-                logits4 = ops.gemm_nt(y, plan.cls)                              # [B*h4*w4, round8(nc)], classifier before the up-sampling
+            logits4, h4, w4 = self._logits4(x)
             full = ops.bilinear_fwd(logits4, b, h4, w4, H, W)
         return full.view(b, H, W, -1)[..., :self.out_channels].permute(0, 3, 1, 2)
+
+    def predict_class_map(self, x: Tensor) -> Tensor:
+        """forward + PredictionWriter's softmax/argmax (helper/callbacks.py:52-54) -> uint8 [B, H, W]; equals
+        ``postproc.class_map(self(x))`` bit for bit, but the full-size logits are never written (the resize and the arg-max are
+        one kernel over the head-resolution logits)."""
+        b, c, H, W = x.shape
+        with torch.no_grad():
+            logits4, h4, w4 = self._logits4(x)
+            return ops.bilinear_class_map(logits4, b, h4, w4, H, W, self.out_channels)
+
+    def _logits4(self, x):
+        """Backbone + head + classifier -> logits [B*h4*w4, round8(nc)] at the finest stage's size (caller holds no_grad)."""
+        b = x.shape[0]
+        plan = self.backbone._plan_for(self, x)
+        feats = list(self.backbone._run(x, plan).values())
+        h4, w4 = max(f[1] for f in feats), max(f[2] for f in feats)         # UniRes target: the largest map (modules/heads.py:78-82)
+        if isinstance(self.head, RefinerHead):
+            logits4 = self._refiner(plan, feats, b, h4, w4)
+        else:
+            if self.fusion == 'sum':
+                if (feats[0][1], feats[0][2]) != (h4, w4):
+                    raise ValueError('TopFormerModel: the first stage must be the finest map')
+                acc = feats[0][0]
+                for t, h, w in feats[1:]:
+                    ops.bilinear_add(t, acc, b, h, w, h4, w4)
+            else:                                                           # Concat(dim=1): stage g fills channel slice g
+                C = feats[0][0].shape[1]
+                acc = torch.empty((b * h4 * w4, C * len(feats)), dtype=plan.T, device=x.device)
+                for g, (t, h, w) in enumerate(feats):
+                    ops.bilinear_fwd(t, b, h, w, h4, w4, out=acc[:, g * C:(g + 1) * C])
+            y = ops.gemm_nt(acc, plan.head[0], bias=plan.head[1], act=RELU6)
+            logits4 = ops.gemm_nt(y, plan.cls)                              # [B*h4*w4, round8(nc)], classifier before the up-sampling
+        return logits4, h4, w4
 
     def _refiner(self, plan, feats, b, h4, w4):
         """RefinerHead.forward (modules/heads.py:255-269) + the classifier (core/models.py:103-115) -> logits at the finest stage's size.
