@@ -221,6 +221,15 @@ int ss_bilinear_class_map_u8(int dtype, const void* x, int64_t ldx, uint8_t* out
 int ss_confusion_labels_u8(const uint8_t* truth, const uint8_t* pred, const uint8_t* valid, const int* lut, int64_t* cm, int64_t n, int C,
                            hipStream_t stream);
 
+/* ---- data_factory/utils.py:6-37 on the device: the batch is uploaded as uint8.
+ * ss_stage_image_u8: image_to_tensor, out[b][c][y][x] = (float(src) - mu[c]) / sigma[c] in fp32 with a correctly rounded division,
+ *   src = uint8 [B][C][H][W] dense, out in out_dtype with element strides (on, oc, oh, ow): NCHW fp32 is the reference tensor bit
+ *   for bit, channels-last compute dtype is what the first layer reads without another pass.  mu, sigma: fp32 [C] on the device.
+ * ss_stage_label_u8: label_to_tensor, uint8 [n] -> int64 [n]. */
+int ss_stage_image_u8(int out_dtype, const uint8_t* src, const float* mu, const float* sigma, void* out, int64_t on, int64_t oc,
+                      int64_t oh, int64_t ow, int B, int C, int H, int W, hipStream_t stream);
+int ss_stage_label_u8(const uint8_t* src, int64_t* out, int64_t n, hipStream_t stream);
+
 /* ---- core/decoder.py:49-59 tail on channels-last maps.  x = LawinHead output [B,H4,W4,2oc].  The host runs two GEMMs on x:
  * z9 [rows, ld9 >= 9*oc] = x . Wd (ConvTranspose2d k3 s4 weight as [(o,dy,dx)][c], modules/blocks.py:224-234) and bs [rows, oc] =
  * conv1x1(x) + b (feature_reducer, core/decoder.py:38-47; the 1x1 conv commutes with the nearest up-sampling of :52-58).

@@ -548,6 +548,77 @@ extern "C" int ss_weight_prep_batch(const int64_t* table_dev, int nent, int64_t 
     return 0;
 }
 
+// ------------------------------------------------------------------ input staging (data_factory/utils.py:6-37)
+// image_to_tensor on the device: out[b, c, y, x] = (float(src[b, c, y, x]) - mu[c]) / sigma[c] in fp32 (correctly rounded
+// division, as torch's), stored in the caller's dtype and strides -- NCHW fp32 reproduces the reference tensor bit for bit, the
+// channels-last compute dtype is what the first layer of this engine reads without another pass.  The batch travels to the
+// device as uint8 (a quarter of the float32 bytes).  A thread owns 4 neighbouring pixels of a row in every channel.
+template <typename T, int CC>                       // CC = 3: RGB into a dense channels-last map, 4 pixels leave as one contiguous run
+__global__ __launch_bounds__(256) void stage_image_u8_kernel(const unsigned char* __restrict__ src, const float* __restrict__ mu,
+        const float* __restrict__ sigma, T* __restrict__ out, int64_t on, int64_t oc, int64_t oh, int64_t ow, int C, int H, int W, int64_t quads) {
+    const int wq = (W + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
+        const int xq = (int)(q % wq);
+        const int64_t rowi = q / wq;                                 // b * H + y
+        const int y = (int)(rowi % H);
+        const int64_t b = rowi / H;
+        const int x0 = xq * 4, nx = min(4, W - x0);
+        if (CC > 0 && nx == 4) {
+            union { T v[4 * CC]; unsigned long long w[(4 * CC * sizeof(T)) / 8]; } o;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const unsigned char* sp = src + ((b * CC + c) * H + y) * (int64_t)W + x0;
+                unsigned char px[4];
+                if ((((uintptr_t)sp) & 3) == 0) *(unsigned*)px = *(const unsigned*)sp;
+                else { px[0] = sp[0]; px[1] = sp[1]; px[2] = sp[2]; px[3] = sp[3]; }
+                const float m = mu[c], sg = sigma[c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o.v[j * CC + c] = from_f<T>(__fdiv_rn((float)px[j] - m, sg));
+            }
+            T* dp = out + b * on + y * oh + (int64_t)x0 * CC;
+            if ((((uintptr_t)dp) & 7) == 0) {
+#pragma unroll
+                for (int k = 0; k < (int)((4 * CC * sizeof(T)) / 8); ++k) ((unsigned long long*)dp)[k] = o.w[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4 * CC; ++k) dp[k] = o.v[k];
+            }
+            continue;
+        }
+        for (int c = 0; c < C; ++c) {
+            const unsigned char* sp = src + ((b * C + c) * H + y) * (int64_t)W + x0;
+            unsigned char px[4] = {0, 0, 0, 0};
+            if (nx == 4 && (((uintptr_t)sp) & 3) == 0) *(unsigned*)px = *(const unsigned*)sp;
+            else for (int j = 0; j < nx; ++j) px[j] = sp[j];
+            const float m = mu[c], sg = sigma[c];
+            T* dp = out + b * on + c * oc + y * oh + x0 * ow;
+            for (int j = 0; j < nx; ++j) dp[j * ow] = from_f<T>(__fdiv_rn((float)px[j] - m, sg));
+        }
+    }
+}
+__global__ void widen_u8_i64_kernel(const unsigned char* __restrict__ src, long long* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = src[i];
+}
+extern "C" int ss_stage_image_u8(int out_dtype, const uint8_t* src, const float* mu, const float* sigma, void* out, int64_t on, int64_t oc,
+                                 int64_t oh, int64_t ow, int B, int C, int H, int W, hipStream_t stream) {
+    SS_CHECK(src && mu && sigma && out && B > 0 && C > 0 && H > 0 && W > 0, "ss_stage_image_u8: bad arguments");
+    const int64_t quads = (int64_t)B * H * ((W + 3) / 4);
+    if (C == 3 && oc == 1 && ow == 3)
+        SS_DISPATCH(out_dtype, hipLaunchKernelGGL((stage_image_u8_kernel<T, 3>), dim3(nblocks(quads, 16384)), dim3(256), 0, stream, src, mu, sigma,
+                                                  (T*)out, on, oc, oh, ow, C, H, W, quads));
+    else
+        SS_DISPATCH(out_dtype, hipLaunchKernelGGL((stage_image_u8_kernel<T, 0>), dim3(nblocks(quads, 16384)), dim3(256), 0, stream, src, mu, sigma,
+                                                  (T*)out, on, oc, oh, ow, C, H, W, quads));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_stage_label_u8(const uint8_t* src, int64_t* out, int64_t n, hipStream_t stream) {
+    SS_CHECK(src && out && n > 0, "ss_stage_label_u8: bad arguments");
+    hipLaunchKernelGGL(widen_u8_i64_kernel, dim3(nblocks(n, 16384)), dim3(256), 0, stream, src, (long long*)out, n);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------ DropPath multiplier (modules/helpers.py:17-24)
 // keep[i] = floor(kp + u[i]) / kp with u the torch.rand draw in the activation dtype: the sum is rounded to that dtype before the
 // floor, as `kp + torch.rand(shape, dtype=x.dtype)` does, and the division is torch's scalar form (a multiply by 1 / kp in fp32).

@@ -656,6 +656,36 @@ def confusion_labels(truth, pred, lut, C, valid=None, cm=None):
     return cm
 
 
+def stage_image(src, mu, sigma, dtype, channels_last):
+    """uint8 [B, C, H, W] -> (src - mu[c]) / sigma[c] as a [B, C, H, W] tensor of `dtype`: dense NCHW, or the permuted view of a
+    dense [B, H, W, C] map (what runtime.as_tokens_nhwc takes without a copy)."""
+    dev = _dev(src)
+    if src.dtype != torch.uint8 or src.dim() != 4 or not src.is_contiguous():
+        raise ValueError('stage_image: src must be a contiguous uint8 [B, C, H, W] tensor')
+    B, C, H, W = src.shape
+    for name, t in (('mu', mu), ('sigma', sigma)):
+        if t.dtype != torch.float32 or t.shape != (C,) or not t.is_contiguous() or t.device != dev:
+            raise ValueError(f'stage_image: {name} must be a contiguous float32 [{C}] tensor on the device')
+    if channels_last:
+        out = torch.empty((B, H, W, C), dtype=dtype, device=dev).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((B, C, H, W), dtype=dtype, device=dev)
+    on, oc, oh, ow = out.stride()
+    check(lib().ss_stage_image_u8(_DT[dtype], _p(src), _p(mu), _p(sigma), _p(out), on, oc, oh, ow, B, C, H, W, _stream()))
+    return out
+
+
+def stage_label(src):
+    """uint8 labels (any shape) -> int64."""
+    dev = _dev(src)
+    if src.dtype != torch.uint8 or not src.is_contiguous():
+        raise ValueError('stage_label: src must be a contiguous uint8 tensor')
+    out = torch.empty(src.shape, dtype=torch.int64, device=dev)
+    if src.numel():
+        check(lib().ss_stage_label_u8(_p(src), _p(out), src.numel(), _stream()))
+    return out
+
+
 def colsum_any(x):
     """[rows, C] -> [C] fp32 column sums for any C (narrow tensors use the scalar kernel)."""
     rows, C, ld = _mat(x, 'x')

@@ -55,3 +55,17 @@ cm = confusion_matrix(y_true=a, y_pred=b, labels=list(range(6)), normalize=None)
 t_sk = time.perf_counter() - t0
 assert np.array_equal(cm, st['cm']) and np.allclose(f1, st['f1'], atol=1e-12) and np.allclose(io, st['iou'], atol=1e-12)
 print(f'sklearn f1 + jaccard + confusion_matrix on the CPU, 1 image pair: {1e3 * t_sk:.0f} ms')
+# input staging (data_factory/utils.py:6-37) at the headline batch: 16 x 3 x 1024 x 1024
+from semseg_amd import datastage
+u8 = torch.randint(0, 256, (16, 3, 1024, 1024), generator=g, device='cuda', dtype=torch.uint8)
+n = u8.numel()
+us = timed(lambda: datastage.image_to_tensor(u8, dtype=torch.bfloat16))
+print(f'{"image_to_tensor uint8 -> bf16 channels-last":44s} {us:8.1f} us  {n * 3 / us / 1e6:6.2f} TB/s   (upload {n / 1e6:.0f} MB instead of {4 * n / 1e6:.0f} MB)')
+us = timed(lambda: datastage.image_to_tensor(u8, dtype=torch.float32))
+print(f'{"image_to_tensor uint8 -> fp32 NCHW":44s} {us:8.1f} us  {n * 5 / us / 1e6:6.2f} TB/s')
+lab = torch.randint(0, 6, (16, 1024, 1024), generator=g, device='cuda', dtype=torch.uint8)
+us = timed(lambda: datastage.label_to_tensor(lab))
+print(f'{"label_to_tensor uint8 -> int64":44s} {us:8.1f} us  {lab.numel() * 9 / us / 1e6:6.2f} TB/s')
+x1 = u8[0].cpu().numpy()
+t0 = time.perf_counter(); ref = (torch.from_numpy(x1) - torch.zeros(3, 1, 1)) / torch.full((3, 1, 1), 255.0); t_ref = time.perf_counter() - t0
+print(f'reference image_to_tensor on the CPU, 1 tile of 3 x 1024 x 1024: {1e3 * t_ref:.2f} ms')
