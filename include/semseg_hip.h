@@ -260,6 +260,13 @@ int ss_terminator_bwd(int dtype, const void* dprobs, const void* prod, const flo
  * out = local * bilinear(gact) + bilinear(gemb).  ss_bilinear_add: y += bilinear(x) (UniRes + Sum, modules/heads.py:60-106). */
 int ss_im2col_ex(int dtype, const void* x, void* col, int B, int H, int W, int C, int k, int s, int pad_top, int pad_left, int Ho,
                  int Wo, int Kp, hipStream_t stream);
+/* Stem of the token pyramid without the staging pass and the im2col matrix: Conv(3 -> 16, k3, s2, AutoPadding) + folded BN + act
+ * (modules/topformer.py:1023-1033) straight from the image.  x: fp32 (in_dtype 0) or compute-dtype image with element strides
+ * (sn, sc, sh, sw) -- NCHW or channels-last; wp: [16][Kp] packed weight of ss_pack_conv_weight (columns (ky, kx, c)) in dtype;
+ * y: [B*Ho*Wo][16] in dtype.  Inputs are rounded to dtype on entry, as ss_nchw_to_nhwc would have stored them. */
+int ss_stem_conv3x3s2(int dtype, int in_dtype, const void* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const void* wp, int Kp,
+                      const float* bias, void* y, int B, int Cin, int H, int W, int pad_top, int pad_left, int Ho, int Wo, int act,
+                      hipStream_t stream);
 int ss_avgpool(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C, int win, hipStream_t stream);
 int ss_act(int dtype, const void* x, void* y, int64_t n, int act, hipStream_t stream);
 int ss_inject_fuse(int dtype, const void* local, int64_t ldl, const void* gact, int64_t lda, const void* gemb, int64_t lde, void* out,

@@ -114,6 +114,92 @@ __global__ __launch_bounds__(256) void bilinear_add_kernel(const T* __restrict__
 static inline int tf_blocks(int64_t n, int cap = 32768) { int64_t b = cdiv(n, 256); return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
 static inline bool ok8(const void* p, int64_t ld) { return aligned16(p) && ld % 8 == 0; }
 
+// Stem of the token pyramid (modules/topformer.py:1023-1033: Conv 3 -> 16, k3, s2, AutoPadding, folded BN, ReLU) straight from
+// the image: no channels-last staging pass, no im2col matrix (at 2048 x 2048 those were 0.1 + 0.42 ms and 270 MB per batch of 4
+// next to a 0.15 ms GEMM).  A thread owns one output pixel and its 16 channels; the 27 x 16 weights sit in LDS as fp32 and are
+// read as broadcasts; inputs are rounded to the compute dtype on entry, exactly what the staging pass stored, and the packed
+// weight is the GEMM's own operand, so only the fp32 summation order differs from the im2col + GEMM path.
+template <typename T, typename TI, int CIN>
+__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const TI* __restrict__ x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+        const T* __restrict__ wp, int Kp, const float* __restrict__ bias, T* __restrict__ y, int H, int W, int ho, int wo, int pt, int pl,
+        int act, int64_t pairs) {
+    constexpr int KK = 9 * CIN;
+    __shared__ __attribute__((aligned(16))) float wsm[KK * 16];
+    for (int i = threadIdx.x; i < KK * 16; i += 256) wsm[i] = to_f(wp[(int64_t)(i & 15) * Kp + (i >> 4)]);
+    __syncthreads();
+    // one thread = two neighbouring output pixels (they share an input column and every weight read); no loop over pixels and a
+    // rolled loop over kernel rows: fully unrolled, the compiler loads all 432 weights up front (256 VGPRs + 1.5 KB of spills)
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= pairs) return;
+    const int wo2 = (wo + 1) >> 1;
+    const int oxp = (int)(p % wo2); const int64_t q = p / wo2; const int oy = (int)(q % ho); const int64_t b = q / ho;
+    const int ox0 = oxp * 2;
+    float acc[2][16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[0][o] = acc[1][o] = bias ? bias[o] : 0.f;
+    const TI* xb = x + b * sn;
+#pragma unroll 1                                            // a real loop: one kernel row's 9 x 16 weights in registers at a time
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - pt + ky;
+        const bool yin = iy >= 0 && iy < H;
+        float v[5][CIN];
+#pragma unroll
+        for (int jx = 0; jx < 5; ++jx) {
+            const int ix = ox0 * 2 - pl + jx;
+            const bool in = yin && ix >= 0 && ix < W;
+            const TI* px = xb + (in ? iy * sh + ix * sw : 0);
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) { const float t = to_f(from_f<T>((float)px[c * sc])); v[jx][c] = in ? t : 0.f; }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const floatx4* wr = (const floatx4*)(wsm + ((ky * 3 + kx) * CIN + c) * 16);
+                const floatx4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][e] = fmaf(v[kx][c], w0[e], acc[0][e]);           acc[1][e] = fmaf(v[kx + 2][c], w0[e], acc[1][e]);
+                    acc[0][4 + e] = fmaf(v[kx][c], w1[e], acc[0][4 + e]);   acc[1][4 + e] = fmaf(v[kx + 2][c], w1[e], acc[1][4 + e]);
+                    acc[0][8 + e] = fmaf(v[kx][c], w2[e], acc[0][8 + e]);   acc[1][8 + e] = fmaf(v[kx + 2][c], w2[e], acc[1][8 + e]);
+                    acc[0][12 + e] = fmaf(v[kx][c], w3[e], acc[0][12 + e]); acc[1][12 + e] = fmaf(v[kx + 2][c], w3[e], acc[1][12 + e]);
+                }
+            }
+    }
+    T* dst = y + ((q * wo) + ox0) * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (ox0 + h >= wo) break;
+        F8 lo, hi;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) { lo.v[o] = apply_act(acc[h][o], act); hi.v[o] = apply_act(acc[h][8 + o], act); }
+        store8(dst + h * 16, lo);
+        store8(dst + h * 16 + 8, hi);
+    }
+}
+
+extern "C" int ss_stem_conv3x3s2(int dtype, int in_dtype, const void* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const void* wp, int Kp,
+                                 const float* bias, void* y, int B, int Cin, int H, int W, int pad_top, int pad_left, int Ho, int Wo, int act,
+                                 hipStream_t stream) {
+    SS_CHECK(x && wp && y && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Kp >= 9 * Cin, "ss_stem_conv3x3s2: bad arguments");
+    SS_CHECK(Cin == 3, "ss_stem_conv3x3s2: built for 3 input channels (got %d)", Cin);
+    SS_CHECK(in_dtype == SS_F32 || in_dtype == dtype, "ss_stem_conv3x3s2: the image is fp32 or already in the compute dtype");
+    SS_CHECK(act >= 0 && act <= 5 && aligned16(y), "ss_stem_conv3x3s2: bad activation or unaligned output");
+    SS_CHECK((Ho - 1) * 2 - pad_top < H && (Wo - 1) * 2 - pad_left < W, "ss_stem_conv3x3s2: output larger than the padded image allows");
+    const int64_t total = (int64_t)B * Ho * ((Wo + 1) / 2);                 // pixel pairs, one per thread
+    SS_CHECK(cdiv(total, 256) < 2147483647LL, "ss_stem_conv3x3s2: image too large");
+    dim3 grid((unsigned)cdiv(total, 256));
+    if (in_dtype == SS_F32) {
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((stem_conv_kernel<T, float, 3>), grid, dim3(256), 0, stream, (const float*)x, sn, sc, sh, sw, (const T*)wp,
+                                              Kp, bias, (T*)y, H, W, Ho, Wo, pad_top, pad_left, act, total));
+    } else {
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((stem_conv_kernel<T, T, 3>), grid, dim3(256), 0, stream, (const T*)x, sn, sc, sh, sw, (const T*)wp, Kp, bias,
+                                              (T*)y, H, W, Ho, Wo, pad_top, pad_left, act, total));
+    }
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ss_im2col_ex(int dtype, const void* x, void* col, int B, int H, int W, int C, int k, int s, int pad_top, int pad_left, int Ho,
                             int Wo, int Kp, hipStream_t stream) {
     SS_CHECK(x && col && B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && s > 0 && Ho > 0 && Wo > 0 && Kp >= k * k * C, "ss_im2col_ex: bad arguments");

@@ -841,6 +841,20 @@ def im2col_ex(x, B, H, W, C, k, s, pad_top, pad_left, Ho, Wo):
     return col
 
 
+def stem_conv(x, wp, bias, pad_top, pad_left, Ho, Wo, dtype, act=0):
+    """x [B, 3, H, W] (fp32 or `dtype`, any dense layout) -> [B*Ho*Wo, 16] in `dtype`: 3x3 / stride 2 conv with the packed weight
+    wp [16, Kp] of pack_conv_weight + bias + activation, no im2col matrix."""
+    dev = _dev(x)
+    B, C, H, W = x.shape
+    if x.dtype not in (torch.float32, dtype) or wp.dtype != dtype or wp.shape[0] != 16 or not wp.is_contiguous():
+        raise ValueError('stem_conv: x must be fp32 or the compute dtype, wp a contiguous [16, Kp] matrix in the compute dtype')
+    y = torch.empty((B * Ho * Wo, 16), dtype=dtype, device=dev)
+    sn, sc, sh, sw = x.stride()
+    check(lib().ss_stem_conv3x3s2(_DT[dtype], _DT[x.dtype], _p(x), sn, sc, sh, sw, _p(wp), wp.shape[1], _p(bias) if bias is not None else None,
+                                  _p(y), B, C, H, W, pad_top, pad_left, Ho, Wo, act, _stream()))
+    return y
+
+
 def avgpool(x, B, H, W, win, out=None):
     dev = _dev(x)
     rows, C, ldx = _mat(x, 'x')

@@ -257,11 +257,15 @@ class TopFormerBackBone(nn.Module):
         """x: fp32 NCHW image -> OrderedDict stage -> (tokens [B*h*w, C], h, w)."""
         net, T = self.net, plan.T
         B, cin, H, W = x.shape
-        t = ops.nchw_to_nhwc(x.contiguous().float(), T)
         pt, _ = auto_pad(3, 2)
         h, w = H // 2, W // 2
-        col = ops.im2col_ex(t, B, H, W, cin, 3, 2, pt, pt, h, w)
-        y = ops.gemm_nt(col, plan.stem[0], bias=plan.stem[1], act=RELU)
+        if cin == 3 and plan.stem[0].shape[0] == 16:                 # every reference config: the stem reads the image itself
+            xs = x if x.dtype in (torch.float32, T) and (x.is_contiguous() or x.permute(0, 2, 3, 1).is_contiguous()) else x.contiguous().float()
+            y = ops.stem_conv(xs, plan.stem[0], plan.stem[1], pt, pt, h, w, T, act=RELU)
+        else:
+            t = ops.nchw_to_nhwc(x.contiguous().float(), T)
+            col = ops.im2col_ex(t, B, H, W, cin, 3, 2, pt, pt, h, w)
+            y = ops.gemm_nt(col, plan.stem[0], bias=plan.stem[1], act=RELU)
         pyr = OrderedDict()
         names = iter(net.stage_names)
         for ent in plan.blocks:

@@ -133,3 +133,29 @@ def test_refiner_pieces_against_torch():
     s = val.view(b, n, groups * cg).sigmoid().permute(0, 2, 1).reshape(b, groups * cg, n, 1)
     want = torch.einsum('ro,bon->bnr', L, gn(s).detach().view(b, groups * cg, n))
     assert got.shape == (b * n, 24) and rel(got.view(b, n, 24)[..., :19], want) < 1e-4 and float(got[:, 19:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('hw', [(64, 96), (37, 51)])
+def test_stem_conv_direct_vs_torch_and_vs_im2col_gemm(dtype, hw):
+    """The direct stem kernel (image -> 16 channels, k3 s2, AutoPadding (0, 1)) against torch's conv2d on the CPU in fp32 and
+    against the im2col + GEMM path it replaces; fp32 1e-5, bf16 one rounding of the output (2^-8 relative)."""
+    import torch.nn.functional as F
+    from semseg_amd import ops
+    H, W = hw
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand((2, 3, H, W), generator=g)
+    w = torch.randn((16, 3, 3, 3), generator=g) * 0.3
+    b = torch.randn(16, generator=g) * 0.1
+    ho, wo = H // 2, W // 2
+    ref = F.relu(F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2))[:, :, :ho, :wo]
+    wp = ops.pack_conv_weight(w.cuda(), dtype, transposed=False)[0]
+    y = ops.stem_conv(x.cuda(), wp, b.cuda(), 0, 0, ho, wo, dtype, act=2)
+    got = y.view(2, ho, wo, 16).permute(0, 3, 1, 2).float().cpu()
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((got - ref).abs().max() / ref.abs().max()) < tol
+    t = ops.nchw_to_nhwc(x.cuda(), dtype)
+    old = ops.gemm_nt(ops.im2col_ex(t, 2, H, W, 3, 3, 2, 0, 0, ho, wo), wp, bias=b.cuda(), act=2)
+    assert float((y.float() - old.float()).abs().max() / old.float().abs().max()) < (1e-5 if dtype == torch.float32 else 2.0 ** -7)
+    staged = t.view(2, H, W, 3).permute(0, 3, 1, 2)                    # channels-last compute-dtype image (datastage.image_to_tensor)
+    assert torch.equal(ops.stem_conv(staged, wp, b.cuda(), 0, 0, ho, wo, dtype, act=2), y)
