@@ -135,6 +135,7 @@ def test_refiner_pieces_against_torch():
     assert got.shape == (b * n, 24) and rel(got.view(b, n, 24)[..., :19], want) < 1e-4 and float(got[:, 19:].abs().max()) == 0.0
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('hw', [(64, 96), (37, 51)])
 def test_stem_conv_direct_vs_torch_and_vs_im2col_gemm(dtype, hw):
