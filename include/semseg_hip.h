@@ -40,6 +40,11 @@ int ss_version(void);
 int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldr,
                const float* rowscale, int64_t rows_per_scale, int act, hipStream_t stream);
+/* Linear + GELU with both tensors kept (modules/convnext.py:43-45, pw_conv1 -> act: the backward needs the pre-activation for GELU'
+ * and the activation for pw_conv2's weight gradient): Z [M, ldz] = A . B^T + bias, G [M, ldg] = GELU_erf(Z as stored).  bf16 tile
+ * kernels write both from one epilogue; other shapes / fp32 (dense Z, G) run ss_gemm_nt and ss_gelu_fwd.  Bit-identical either way. */
+int ss_gemm_nt_gelu2(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* Z, int64_t ldz, void* G, int64_t ldg,
+                     int64_t M, int64_t N, int64_t K, const float* bias, hipStream_t stream);
 /* weight gradient of the same layers: C[M,N] (fp32) (+)= sum_r A[r,M]^T . B[r,N]; deterministic split-R slab reduce. */
 int64_t ss_gemm_tn_workspace(int dtype, int64_t M, int64_t N, int64_t R);
 int ss_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
@@ -102,6 +107,10 @@ int ss_dwconv3_bwd(int dtype, const void* dy, const void* x, const float* w9c, c
  * symmetric padding, k in {3,5,7}; workspace >= 1024*(k*k+1)*C floats. */
 int ss_dwconvk_fwd(int dtype, const void* x, const float* wkkc, const float* bias, void* y, int B, int H, int W, int C, int k,
                    int stride, int pad_top, int pad_left, int Ho, int Wo, int act, hipStream_t stream);
+/* The same with a residual: y = act(dw(x) + bias) + res, res shaped like y.  modules/convnext.py:36-50 backward: the gradient of the
+ * block's skip connection joins the depthwise data gradient in the kernel that produces it (was a separate add pass). */
+int ss_dwconvk_fwd_res(int dtype, const void* x, const float* wkkc, const float* bias, const void* res, void* y, int B, int H, int W,
+                       int C, int k, int stride, int pad_top, int pad_left, int Ho, int Wo, int act, hipStream_t stream);
 int ss_dwconvk_wgrad(int dtype, const void* g, const void* x, float* dw_db, int B, int H, int W, int C, int k, int pad,
                      float* workspace, int64_t ws_bytes, hipStream_t stream);
 /* out[r] = sum_c a[r][c] * b[r][c] (fp32): layer-scale gradient of modules/convnext.py:33-35,46-47 from the folded weight gradient */

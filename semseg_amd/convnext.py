@@ -74,8 +74,7 @@ class _BlockFn(_ParamFn):
         w49 = w_taps(P['dw_conv.weight'])
         d = ops.dwconvk_fwd(x, w49, P['dw_conv.bias'], B, h, w, 7)
         n, m, r = ops.layernorm_fwd(d, P['norm.weight'], P['norm.bias'], 1e-6)
-        z1 = ops.gemm_nt(n, w_fwd(P['pw_conv1.weight'], T), bias=P['pw_conv1.bias'])
-        a = ops.gelu_fwd(z1)
+        z1, a = ops.gemm_nt_gelu2(n, w_fwd(P['pw_conv1.weight'], T), bias=P['pw_conv1.bias'])     # pre-activation and GELU from one epilogue
         gamma = P.get('gamma')
         w2, b2 = P['pw_conv2.weight'].detach(), P['pw_conv2.bias'].detach()
         if gamma is not None:                                # fold the layer scale into the projection (parameter-sized work)
@@ -109,7 +108,7 @@ class _BlockFn(_ParamFn):
         G['dw_conv.weight'] = ops.transpose_cast(dwdb[:49].contiguous(), torch.float32).reshape(C, 1, 7, 7)
         G['dw_conv.bias'] = dwdb[49]
         flip = w_taps(P['dw_conv.weight'], reverse=True)
-        dx = ops.add(ops.dwconvk_fwd(dd, flip, None, B, h, w, 7), dout)
+        dx = ops.dwconvk_fwd(dd, flip, None, B, h, w, 7, res=dout if dout.is_contiguous() else dout.contiguous())   # + the skip path's gradient
         return dx, G
 
 

@@ -11,7 +11,7 @@
 
 template <typename T>
 __global__ __launch_bounds__(256) void dwconvk_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-        T* __restrict__ y, int B, int H, int W, int C, int k, int stride, int pt, int pl, int Ho, int Wo, int act) {
+        T* __restrict__ y, int B, int H, int W, int C, int k, int stride, int pt, int pl, int Ho, int Wo, int act, const T* __restrict__ res) {
     const int chunks = C / 8;
     const int64_t total = (int64_t)B * Ho * Wo * chunks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void dwconvk_fwd_kernel(const T* __restrict__ 
         for (int e = 0; e < 8; ++e) {
             o.v[e] = apply_act(u[e], act);
         }
+        if (res) { const F8 r = load8(res + p * C + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] += r.v[e]; }
         store8(y + p * C + c, o);
     }
 }
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void dwconvk_fwd_kernel(const T* __restrict__ 
 // conversions per 8-channel output instead of 49 global loads).
 template <typename T, int K, int ACT>
 __global__ __launch_bounds__(256) void dwconvk_tile_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-        T* __restrict__ y, int H, int W, int C, int pt, int pl, int Ho, int Wo, int tiles_x, int tiles_y) {
+        T* __restrict__ y, int H, int W, int C, int pt, int pl, int Ho, int Wo, int tiles_x, int tiles_y, const T* __restrict__ res) {
     constexpr int TW = 64, RPT = 8, ROWS = RPT + K - 1, COLS = TW + K - 1;
     __shared__ __attribute__((aligned(16))) T smem[4 * ROWS * COLS * 8];
     __shared__ __attribute__((aligned(16))) float wsm[K * K * 32];          // this channel group's taps: broadcast LDS reads in the tap loop
@@ -123,7 +126,11 @@ __global__ __launch_bounds__(256) void dwconvk_tile_kernel(const T* __restrict__
                 F8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o.v[e] = apply_act(acc[j][e], ACT);
-                store8(y + (((int64_t)b * Ho + gy) * Wo + gx) * C + c0, o);
+                const int64_t at = (((int64_t)b * Ho + gy) * Wo + gx) * C + c0;
+                if (res) { const F8 r = load8(res + at);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o.v[e] += r.v[e]; }
+                store8(y + at, o);
             }
         }
     }
@@ -131,10 +138,10 @@ __global__ __launch_bounds__(256) void dwconvk_tile_kernel(const T* __restrict__
 
 template <typename T, int K>
 static void dwconvk_tile_launch(const T* x, const float* w, const float* bias, T* y, int B, int H, int W, int C, int pt, int pl, int Ho, int Wo,
-                                int act, hipStream_t stream) {
+                                int act, const T* res, hipStream_t stream) {
     const int tiles_x = (int)cdiv(Wo, 64), tiles_y = (int)cdiv(Ho, 8);
     dim3 grid((unsigned)(B * tiles_x * tiles_y), (unsigned)(C / 32));
-#define SS_DWT(ACT) hipLaunchKernelGGL((dwconvk_tile_kernel<T, K, ACT>), grid, dim3(256), 0, stream, x, w, bias, y, H, W, C, pt, pl, Ho, Wo, tiles_x, tiles_y)
+#define SS_DWT(ACT) hipLaunchKernelGGL((dwconvk_tile_kernel<T, K, ACT>), grid, dim3(256), 0, stream, x, w, bias, y, H, W, C, pt, pl, Ho, Wo, tiles_x, tiles_y, res)
     switch (act) { case 1: SS_DWT(1); break; case 2: SS_DWT(2); break; case 3: SS_DWT(3); break; default: SS_DWT(0); break; }
 #undef SS_DWT
 }
@@ -290,8 +297,9 @@ __global__ __launch_bounds__(256) void dwconvk_wgrad_tile_kernel(const T* __rest
     if (lane == 0) { dst[K * K * C] = b0; dst[K * K * C + 1] = b1; }
 }
 
-extern "C" int ss_dwconvk_fwd(int dtype, const void* x, const float* wkkc, const float* bias, void* y, int B, int H, int W, int C, int k,
-                              int stride, int pad_top, int pad_left, int Ho, int Wo, int act, hipStream_t stream) {
+static int dwconvk_fwd_impl(int dtype, const void* x, const float* wkkc, const float* bias, void* y, int B, int H, int W, int C, int k,
+                           int stride, int pad_top, int pad_left, int Ho, int Wo, int act, const void* res, hipStream_t stream) {
+    SS_CHECK(!res || aligned16(res), "ss_dwconvk_fwd_res: res must be 16-byte aligned");
     SS_CHECK(x && wkkc && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && k >= 1 && k <= 15 && stride >= 1 && Ho > 0 && Wo > 0,
              "ss_dwconvk_fwd: bad arguments (C=%d k=%d stride=%d)", C, k, stride);
     SS_CHECK(aligned16(x) && aligned16(y) && aligned16(wkkc) && (!bias || aligned16(bias)), "ss_dwconvk_fwd: pointers must be 16-byte aligned");
@@ -301,17 +309,27 @@ extern "C" int ss_dwconvk_fwd(int dtype, const void* x, const float* wkkc, const
     if (stride == 1 && C % 32 == 0 && (k == 3 || k == 5 || k == 7) && act >= 0 && act <= 3 && (!bias || aligned16(bias)) &&
         (int64_t)B * cdiv(Wo, 64) * cdiv(Ho, 8) < (1LL << 31)) {
         SS_DISPATCH(dtype, {
-            if (k == 3) dwconvk_tile_launch<T, 3>((const T*)x, wkkc, bias, (T*)y, B, H, W, C, pad_top, pad_left, Ho, Wo, act, stream);
-            else if (k == 5) dwconvk_tile_launch<T, 5>((const T*)x, wkkc, bias, (T*)y, B, H, W, C, pad_top, pad_left, Ho, Wo, act, stream);
-            else dwconvk_tile_launch<T, 7>((const T*)x, wkkc, bias, (T*)y, B, H, W, C, pad_top, pad_left, Ho, Wo, act, stream);
+            if (k == 3) dwconvk_tile_launch<T, 3>((const T*)x, wkkc, bias, (T*)y, B, H, W, C, pad_top, pad_left, Ho, Wo, act, (const T*)res, stream);
+            else if (k == 5) dwconvk_tile_launch<T, 5>((const T*)x, wkkc, bias, (T*)y, B, H, W, C, pad_top, pad_left, Ho, Wo, act, (const T*)res, stream);
+            else dwconvk_tile_launch<T, 7>((const T*)x, wkkc, bias, (T*)y, B, H, W, C, pad_top, pad_left, Ho, Wo, act, (const T*)res, stream);
         });
         SS_LAUNCH_CHECK();
         return 0;
     }
     SS_DISPATCH(dtype, hipLaunchKernelGGL((dwconvk_fwd_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)x, wkkc, bias, (T*)y, B, H, W, C, k,
-                                          stride, pad_top, pad_left, Ho, Wo, act));
+                                          stride, pad_top, pad_left, Ho, Wo, act, (const T*)res));
     SS_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int ss_dwconvk_fwd(int dtype, const void* x, const float* wkkc, const float* bias, void* y, int B, int H, int W, int C, int k,
+                              int stride, int pad_top, int pad_left, int Ho, int Wo, int act, hipStream_t stream) {
+    return dwconvk_fwd_impl(dtype, x, wkkc, bias, y, B, H, W, C, k, stride, pad_top, pad_left, Ho, Wo, act, nullptr, stream);
+}
+// y = act(dw(x) + bias) + res, res shaped like y (ConvNeXt block backward: the skip path's gradient joins the depthwise data gradient)
+extern "C" int ss_dwconvk_fwd_res(int dtype, const void* x, const float* wkkc, const float* bias, const void* res, void* y, int B, int H, int W,
+                                  int C, int k, int stride, int pad_top, int pad_left, int Ho, int Wo, int act, hipStream_t stream) {
+    SS_CHECK(res, "ss_dwconvk_fwd_res: res is null");
+    return dwconvk_fwd_impl(dtype, x, wkkc, bias, y, B, H, W, C, k, stride, pad_top, pad_left, Ho, Wo, act, res, stream);
 }
 
 // dw_db: [(k*k + 1)][C] fp32 (taps tap-major, then the bias gradient); stride 1, symmetric padding; workspace >= 1024*(k*k+1)*C floats

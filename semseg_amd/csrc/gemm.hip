@@ -326,6 +326,28 @@ extern "C" int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, co
     return ss_fail(-1, "ss_gemm_nt: unsupported dtype %d", dtype);
 }
 
+extern "C" int ss_gelu_fwd(int dtype, const void* z, void* a, int64_t n, hipStream_t stream);
+
+// Linear + GELU with BOTH tensors kept (modules/convnext.py:43-45: pw_conv1 -> act; the backward needs the pre-activation for
+// GELU' and the activation for pw_conv2's weight gradient): Z = A . B^T + bias, G = GELU(Z as stored).  On the bf16 tile kernels
+// the two stores share one epilogue (no second pass over Z); other shapes / fp32 run the GEMM and then ss_gelu_fwd.
+extern "C" int ss_gemm_nt_gelu2(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* Z, int64_t ldz, void* G, int64_t ldg,
+                                int64_t M, int64_t N, int64_t K, const float* bias, hipStream_t stream) {
+    SS_CHECK(A && B && Z && G && M > 0 && N > 0 && K > 0 && N < (1 << 30) && lda >= K && ldb >= K && ldz >= N && ldg >= N,
+             "ss_gemm_nt_gelu2: bad arguments");
+    SS_CHECK(cdiv(M, 128) * cdiv(N, 64) < 2147483647LL, "ss_gemm_nt_gelu2: too many tiles");
+    if (dtype == SS_BF16 && ldg % 8 == 0 && aligned16(G)) {
+        FastGemm f{};
+        f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = G; f.M = M; f.N = (int)N; f.K = K; f.lda = lda; f.ldb = ldb; f.ldc = ldg;
+        f.bias = bias; f.rows_per_scale = 1; f.act = 0; f.k_per_split = K; f.C2 = (bf16*)Z; f.ldc2 = ldz;
+        if (!ss_skinny_nt_ok(f) && ss_fast_nt_ok(A, lda, B, ldb, Z, ldz, M, N, K, nullptr, 0, bias)) return ss_fast_nt_launch(f, stream);
+    }
+    SS_CHECK(ldz == N && ldg == N && (M * N) % 8 == 0, "ss_gemm_nt_gelu2: outside the bf16 tile kernels Z and G must be dense and M*N a multiple of 8");
+    int rc = ss_gemm_nt(dtype, 0, A, lda, B, ldb, Z, ldz, M, N, K, bias, nullptr, 0, nullptr, 0, 0, stream);
+    if (rc) return rc;
+    return ss_gelu_fwd(dtype, Z, G, M * N, stream);
+}
+
 static int tn_big_enabled() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("SS_GEMM_TN_BIG"); on = !(e && e[0] == '0'); }

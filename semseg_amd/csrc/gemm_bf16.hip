@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(FastGemm p) {
 #pragma unroll
     for (int ps = 0; ps < BM / RPP; ++ps) {
         int row = ps * RPP + erow;
-        if (m0 + row < p.M && ncol_ok)
-            *(bf16x8*)(C + (m0 + row) * p.ldc + n0 + ech * 8) = *(const bf16x8*)(smem + row * EP + ech * 16);
+        if (m0 + row < p.M && ncol_ok) nt_store_chunk(p, C, m0 + row, n0 + ech * 8, *(const bf16x8*)(smem + row * EP + ech * 16));
     }
 }
 

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(FastGemm p) {
     for (int ps = 0; ps < BM / RPP; ++ps) {
         int row = ps * RPP + erow;
         if (m0 + row < p.M && ncol_ok && (!(p.dbg & 1) || acc[0][0][0] == 12345.f))
-            *(bf16x8*)(C + (m0 + row) * p.ldc + n0 + ech * 8) = *(const bf16x8*)(smem + row * EP + ech * 16);
+            nt_store_chunk(p, C, m0 + row, n0 + ech * 8, *(const bf16x8*)(smem + row * EP + ech * 16));
     }
 }
 

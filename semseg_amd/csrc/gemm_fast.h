@@ -12,7 +12,22 @@ struct FastGemm {
     int64_t k_per_split;
     int dbg;
     float* colsum_ws;                       // TN: per-split column sums of A, [nsplit][M] (or null)
+    bf16* C2; int64_t ldc2;                 // NT: second output (or null): C2 gets the tile as the epilogue left it, C gets GELU of it
 };
+
+// Copy-out of one 16-byte chunk of the NT kernels' LDS tile image: plain, or -- when C2 is set -- the pre-activation to C2 and
+// GELU of the (bf16-rounded) pre-activation to C, the very values a separate GELU pass over C2 would have produced.
+__device__ __forceinline__ void nt_store_chunk(const FastGemm& p, bf16* C, int64_t row, int col, const bf16x8& v) {
+    if (p.C2) {
+        *(bf16x8*)(p.C2 + row * p.ldc2 + col) = v;
+        bf16x8 a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (bf16)gelu_erf((float)v[e]);
+        *(bf16x8*)(C + row * p.ldc + col) = a;
+    } else {
+        *(bf16x8*)(C + row * p.ldc + col) = v;
+    }
+}
 bool ss_fast_nt_ok(const void* A, int64_t lda, const void* B, int64_t ldb, const void* C, int64_t ldc, int64_t M, int64_t N,
                    int64_t K, const void* res, int64_t ldr, const float* bias);
 int ss_fast_nt_launch(FastGemm p, hipStream_t st);

@@ -710,8 +710,8 @@ def sum_slices(x, nslices, slice_stride, C, bvec=None, rows_per_image=0):
 
 
 # ------------------------------------------------------------------ general depthwise conv / GELU (ConvNeXt, TopFormer)
-def dwconvk_fwd(x, wkkc, bias, B, H, W, k, stride=1, pad_top=None, pad_left=None, Ho=None, Wo=None, act=0):
-    """x [B*H*W, C] -> y [B*Ho*Wo, C];  wkkc: tap-major [k*k, C] fp32.  Default: symmetric padding k//2, stride 1."""
+def dwconvk_fwd(x, wkkc, bias, B, H, W, k, stride=1, pad_top=None, pad_left=None, Ho=None, Wo=None, act=0, res=None):
+    """x [B*H*W, C] -> y [B*Ho*Wo, C] (+ res, shaped like y);  wkkc: tap-major [k*k, C] fp32.  Default: symmetric padding k//2, stride 1."""
     dev = _dev(x)
     rows, C, ld = _mat(x, 'x')
     if ld != C or rows != B * H * W:
@@ -722,6 +722,12 @@ def dwconvk_fwd(x, wkkc, bias, B, H, W, k, stride=1, pad_top=None, pad_left=None
     Wo = (W + 2 * pad_left - k) // stride + 1 if Wo is None else Wo
     _f32(wkkc, 'wkkc', k * k * C), _f32(bias, 'bias', C)
     y = torch.empty((B * Ho * Wo, C), dtype=x.dtype, device=dev)
+    if res is not None:
+        if res.shape != y.shape or res.dtype != y.dtype or not res.is_contiguous():
+            raise ValueError('dwconvk_fwd: res must be a dense tensor shaped like the output')
+        check(lib().ss_dwconvk_fwd_res(dt(x), _p(x), _p(wkkc), _p(bias), _p(res), _p(y), B, H, W, C, k, stride, pad_top, pad_left, Ho, Wo, act,
+                                       _stream()))
+        return y
     check(lib().ss_dwconvk_fwd(dt(x), _p(x), _p(wkkc), _p(bias), _p(y), B, H, W, C, k, stride, pad_top, pad_left, Ho, Wo, act, _stream()))
     return y
 
@@ -745,6 +751,20 @@ def rowdot_f32(a, b):
     out = torch.empty(rows, dtype=torch.float32, device=a.device)
     check(lib().ss_rowdot_f32(_p(a), _p(b), _p(out), rows, C, _stream()))
     return out
+
+
+def gemm_nt_gelu2(a, w, bias=None):
+    """z = a @ w.T + bias and GELU(z), both kept: -> (z, gelu) in a's dtype (one GEMM epilogue on the bf16 tile kernels)."""
+    dev = _dev(a)
+    M, K, lda = _mat(a, 'a')
+    N, K2, ldb = _mat(w, 'w')
+    if K2 != K or w.dtype != a.dtype:
+        raise ValueError(f'gemm_nt_gelu2: a is [{M}, {K}] {a.dtype}, w is [{N}, {K2}] {w.dtype}')
+    _f32(bias, 'bias', N)
+    z = torch.empty((M, N), dtype=a.dtype, device=dev)
+    g = torch.empty((M, N), dtype=a.dtype, device=dev)
+    check(lib().ss_gemm_nt_gelu2(dt(a), _p(a), lda, _p(w), ldb, _p(z), N, _p(g), N, M, N, K, _p(bias), _stream()))
+    return z, g
 
 
 def gelu_fwd(z):

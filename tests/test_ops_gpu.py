@@ -428,3 +428,38 @@ def test_gemm_nt_gelu_gradient_epilogue(ops, dtype, M, N, K):
     assert rel(out, ref) < _tol(dtype)
     with pytest.raises(RuntimeError):
         ops.gemm_nt(dev(a, dtype), dev(b, dtype), act=ops.GELU_GRAD)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('shape', [(4096, 384, 96), (1000, 768, 192), (640, 3072, 768), (130, 24, 16)])
+def test_gemm_nt_gelu2_equals_gemm_then_gelu(dtype, shape):
+    """Linear + GELU with both outputs from one epilogue == the GEMM followed by the GELU kernel, bit for bit (every tile kernel)."""
+    from semseg_amd import ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn((M, K), generator=g)).to(dtype).cuda()
+    w = (torch.randn((N, K), generator=g) * K ** -0.5).to(dtype).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    z, act = ops.gemm_nt_gelu2(a, w, bias=b)
+    z0 = ops.gemm_nt(a, w, bias=b)
+    assert torch.equal(z, z0) and torch.equal(act, ops.gelu_fwd(z0))
+    ref = torch.nn.functional.gelu(z0.float())
+    assert float((act.float() - ref).abs().max()) < (2e-2 if dtype == torch.bfloat16 else 1e-5) * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('geom', [(2, 24, 40, 64, 7, 1), (1, 9, 70, 32, 3, 1), (2, 16, 16, 24, 5, 2)])
+def test_dwconvk_fwd_with_residual(dtype, geom):
+    """y = dw(x) + res in one kernel (tiled and generic paths) vs the two-step result computed in fp32."""
+    from semseg_amd import ops
+    B, H, W, C, k, s = geom
+    g = torch.Generator().manual_seed(C + k)
+    x = torch.randn((B * H * W, C), generator=g).to(dtype).cuda()
+    w = (torch.randn((k * k, C), generator=g) * 0.2).cuda()
+    y0 = ops.dwconvk_fwd(x.float(), w, None, B, H, W, k, stride=s)
+    res = torch.randn(y0.shape, generator=g).to(dtype).cuda()
+    y = ops.dwconvk_fwd(x, w, None, B, H, W, k, stride=s, res=res)
+    want = y0 + res.float()
+    assert float((y.float() - want).abs().max()) < (2e-2 if dtype == torch.bfloat16 else 1e-5) * max(1.0, float(want.abs().max()))
