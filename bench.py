@@ -400,6 +400,10 @@ def main():
            'loss': float(loss), 'mIoU': float(cm['mIoU']), 'peak_mem_gib': torch.cuda.max_memory_allocated() / 2 ** 30}
     if roof is not None:
         res['roofline'] = roof
+    if table is not None:                                        # the rate with the optimizer step excluded, beside `value`
+        opt_ms = sum(t['ms'] for name, t in table.items() if 'adabound' in name)
+        res['optimizer_ms_per_step'] = opt_ms
+        res['value_without_optimizer'] = a.batch * world / ((ms - opt_ms) * 1e-3)
     if table is not None and a.table:
         tot = sum(t['ms'] for t in table.values())
         for name, t in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
