@@ -341,19 +341,25 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const long long* __restri
 // ------------------------------------------------------------------ confusion matrix: cm[target*C + argmax] += 1  (int64, exact)
 template <typename T>
 __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ logits, Strides s, const long long* __restrict__ labels,
-                                                        unsigned long long* __restrict__ cm, int64_t npix, int H, int W, int C) {
-    extern __shared__ unsigned bins[];           // C*C per block (LDS-privatised)
-    for (int i = threadIdx.x; i < C * C; i += blockDim.x) bins[i] = 0;
+                                                        unsigned long long* __restrict__ cm, int64_t npix, int H, int W, int C, int copies) {
+    extern __shared__ unsigned bins[];           // `copies` private C*C matrices per block: lane l counts in copy l % copies, so the
+    const int cc = C * C;                        // lanes of a wave that meet the same (target, class) pair do not queue on one LDS word
+    for (int i = threadIdx.x; i < cc * copies; i += blockDim.x) bins[i] = 0;
     __syncthreads();
+    unsigned* mine = bins + (threadIdx.x % copies) * cc;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
         const T* p = logits + pix_off(i, H, W, s);
         float best = to_f(p[0]); int arg = 0;
         for (int c = 1; c < C; ++c) { const float v = to_f(p[c * s.c]); if (v > best) { best = v; arg = c; } }   // first max wins
         const long long lab = labels[i];
-        if (lab >= 0 && lab < C) atomicAdd(&bins[(int)lab * C + arg], 1u);
+        if (lab >= 0 && lab < C) atomicAdd(&mine[(int)lab * C + arg], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C * C; i += blockDim.x) if (bins[i]) atomicAdd(&cm[i], (unsigned long long)bins[i]);
+    for (int i = threadIdx.x; i < cc; i += blockDim.x) {
+        unsigned long long t = 0;
+        for (int k = 0; k < copies; ++k) t += bins[k * cc + i];
+        if (t) atomicAdd(&cm[i], t);
+    }
 }
 
 // ------------------------------------------------------------------ prediction writer / evaluation script
@@ -396,24 +402,42 @@ __global__ __launch_bounds__(256) void class_map_kernel(const T* __restrict__ lo
 // pixels `valid` marks (null = all).  lut[256]: raster value -> row / column index, or -1 for a value that is not among
 // `labels` (sklearn drops a pixel whose truth or prediction is not listed).  cm: int64 [C][C], accumulated in place.
 __global__ __launch_bounds__(256) void confusion_labels_kernel(const unsigned char* __restrict__ truth, const unsigned char* __restrict__ pred,
-        const unsigned char* __restrict__ valid, const int* __restrict__ lut, unsigned long long* __restrict__ cm, int64_t n, int C) {
-    extern __shared__ unsigned bins[];
+        const unsigned char* __restrict__ valid, const int* __restrict__ lut, unsigned long long* __restrict__ cm, int64_t n, int C, int copies) {
+    extern __shared__ unsigned bins[];           // `copies` private matrices, lane l counts in copy l % copies (see confusion_kernel)
     __shared__ int slut[256];
+    const int cc = C * C;
     slut[threadIdx.x] = lut[threadIdx.x];
-    for (int i = threadIdx.x; i < C * C; i += blockDim.x) bins[i] = 0;
+    for (int i = threadIdx.x; i < cc * copies; i += blockDim.x) bins[i] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    unsigned* mine = bins + (threadIdx.x % copies) * cc;
+    const bool wide = ((((uintptr_t)truth | (uintptr_t)pred | (uintptr_t)valid) & 3) == 0);
+    const int64_t nq = wide ? n / 4 : 0;                              // 4 pixels per thread through 4-byte loads, then the tail one by one
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned t4 = ((const unsigned*)truth)[q], p4 = ((const unsigned*)pred)[q], v4 = valid ? ((const unsigned*)valid)[q] : 0x01010101u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = slut[(t4 >> (8 * j)) & 255], p = slut[(p4 >> (8 * j)) & 255];
+            if (((v4 >> (8 * j)) & 255) && t >= 0 && p >= 0) atomicAdd(&mine[t * C + p], 1u);
+        }
+    }
+    for (int64_t i = nq * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (valid && !valid[i]) continue;
         const int t = slut[truth[i]], p = slut[pred[i]];
-        if (t >= 0 && p >= 0) atomicAdd(&bins[t * C + p], 1u);
+        if (t >= 0 && p >= 0) atomicAdd(&mine[t * C + p], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C * C; i += blockDim.x) if (bins[i]) atomicAdd(&cm[i], (unsigned long long)bins[i]);
+    for (int i = threadIdx.x; i < cc; i += blockDim.x) {
+        unsigned long long t = 0;
+        for (int k = 0; k < copies; ++k) t += bins[k * cc + i];
+        if (t) atomicAdd(&cm[i], t);
+    }
 }
 
 // ------------------------------------------------------------------ host entry points
 static inline int nblk(int64_t n, int cap) { int64_t b = cdiv(n, 256); return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
 #define CE_REDUCE_BLOCKS 1024
+// private copies of the C x C count matrix per workgroup: up to 16, within 32 KB of LDS
+static inline int cm_copies(int C) { int c = 8192 / (C * C); return c < 1 ? 1 : (c > 16 ? 16 : c); }
 
 // workspace layout helper: all regions 256-byte aligned
 extern "C" int64_t ss_ohem_ce_workspace(int64_t npix) {
@@ -521,8 +545,9 @@ extern "C" int ss_confusion_update(int dtype, const void* logits, int64_t sn, in
     SS_CHECK(logits && labels && cm && B > 0 && C > 0 && C <= 100 && H > 0 && W > 0, "ss_confusion_update: bad arguments (C <= 100)");
     const int64_t npix = (int64_t)B * H * W;
     Strides s{sn, sc, sh, sw};
-    SS_DISPATCH(dtype, hipLaunchKernelGGL((confusion_kernel<T>), dim3(nblk(npix, 2048)), dim3(256), (size_t)C * C * sizeof(unsigned), stream,
-                                          (const T*)logits, s, (const long long*)labels, (unsigned long long*)cm, npix, H, W, C));
+    const int copies = cm_copies(C);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((confusion_kernel<T>), dim3(nblk(npix, 2048)), dim3(256), (size_t)C * C * copies * sizeof(unsigned), stream,
+                                          (const T*)logits, s, (const long long*)labels, (unsigned long long*)cm, npix, H, W, C, copies));
     SS_LAUNCH_CHECK();
     return 0;
 }
@@ -547,8 +572,9 @@ extern "C" int ss_class_map_u8(int dtype, const void* logits, int64_t sn, int64_
 extern "C" int ss_confusion_labels_u8(const uint8_t* truth, const uint8_t* pred, const uint8_t* valid, const int* lut, int64_t* cm, int64_t n,
                                       int C, hipStream_t stream) {
     SS_CHECK(truth && pred && lut && cm && n > 0 && C > 0 && C <= 100, "ss_confusion_labels_u8: bad arguments (1 <= C <= 100)");
-    hipLaunchKernelGGL(confusion_labels_kernel, dim3(nblk(n, 2048)), dim3(256), (size_t)C * C * sizeof(unsigned), stream, truth, pred, valid, lut,
-                       (unsigned long long*)cm, n, C);
+    const int copies = cm_copies(C);
+    hipLaunchKernelGGL(confusion_labels_kernel, dim3(nblk(cdiv(n, 4), 512)), dim3(256), (size_t)C * C * copies * sizeof(unsigned), stream, truth, pred,
+                       valid, lut, (unsigned long long*)cm, n, C, copies);
     SS_LAUNCH_CHECK();
     return 0;
 }
