@@ -236,19 +236,25 @@ __global__ __launch_bounds__(256) void mit_attn_bwd_dkv_kernel(const T* __restri
 
 // dkv[(b*Nk + key)*ldkv + {0,C} + hd*D + dd] = sum_split slab
 template <typename T>
-__global__ void attn_bwd_finish_kernel(const float* __restrict__ dk_slab, const float* __restrict__ dv_slab, T* __restrict__ dkv, int64_t ldkv,
-                                       int B, int Nk, int Nkp, int heads, int D, int C, int nsplit) {
-    const int64_t total = (int64_t)B * Nk * 2 * C;
+__global__ __launch_bounds__(256) void attn_bwd_finish_kernel(const float* __restrict__ dk_slab, const float* __restrict__ dv_slab, T* __restrict__ dkv,
+                                       int64_t ldkv, int B, int Nk, int Nkp, int heads, int D, int C, int nsplit) {
+    // a thread owns 8 consecutive channels of one (image, key) row: D % 8 == 0, so they lie inside one head and are contiguous
+    // in the slab; the splits are summed in a fixed order (deterministic)
+    const int cpr = 2 * C / 8;                                        // 8-channel chunks per output row (dK then dV)
+    const int64_t total = (int64_t)B * Nk * cpr;
     const int64_t slab_sz = (int64_t)B * heads * Nkp * D;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int ch = (int)(i % (2 * C)); int64_t row = i / (2 * C);
-        int key = (int)(row % Nk); int64_t b = row / Nk;
+        const int chunk = (int)(i % cpr); const int64_t row = i / cpr;
+        const int key = (int)(row % Nk); const int64_t b = row / Nk;
+        const int ch = chunk * 8;
         const float* src = ch < C ? dk_slab : dv_slab;
-        int cc = ch < C ? ch : ch - C; int hd = cc / D, dd = cc % D;
-        int64_t off = ((b * heads + hd) * Nkp + key) * D + dd;
-        float s = 0.f;
-        for (int z = 0; z < nsplit; ++z) s += src[z * slab_sz + off];
-        dkv[row * ldkv + ch] = from_f<T>(s);
+        const int cc = ch < C ? ch : ch - C, hd = cc / D, dd = cc % D;
+        const float* p = src + ((b * heads + hd) * Nkp + key) * D + dd;
+        F8 acc = load8(p);
+        for (int z = 1; z < nsplit; ++z) { const F8 v = load8(p + z * slab_sz);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc.v[e] += v.v[e]; }
+        store8(dkv + row * ldkv + ch, acc);
     }
 }
 
@@ -305,7 +311,7 @@ static void attn_bwd_launch(const BwdArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((attn_rowdot_kernel<T>), dim3(rb), dim3(256), 0, stream, (const T*)a.dout, (const T*)a.o, a.delta, rows, N, Np, C, DD, heads);
     dim3 tk((unsigned)cdiv(Nkp, 64), heads, B), tq((unsigned)cdiv(Np, 64), heads, B);
     dim3 gq((unsigned)cdiv(cdiv(N, 32), 4), heads, B), gk((unsigned)cdiv(Nkp / 32, 4), heads, B * a.ns);
-    int64_t tot = (int64_t)B * Nk * 2 * C;
+    int64_t tot = (int64_t)B * Nk * 2 * C / 8;
     int fb = (int)(cdiv(tot, 256) < 4096 ? cdiv(tot, 256) : 4096);
     hipLaunchKernelGGL((attn_transpose_perm_kernel<T, DD>), tk, dim3(256), 0, stream, (const T*)a.kv, (int64_t)2 * C, 0, (T*)a.ktp, Nk, Nkp, heads);
     hipLaunchKernelGGL((attn_transpose_perm_kernel<T, DD>), tq, dim3(256), 0, stream, (const T*)a.q, (int64_t)C, 0, (T*)a.qtp, N, Np, heads);
@@ -367,7 +373,7 @@ extern "C" int ss_mit_attn_bwd(int dtype, const void* q, const void* kv, const v
         f.B = B; f.N = N; f.Np = Np; f.Nk = Nk; f.Nkp = Nkp; f.heads = heads; f.D = D; f.C = C; f.c = c; f.scale = scale; f.ns = ns; f.qps = qps;
         int rc = attn_bwd_bf16_launch(f, stream);
         if (rc) return rc;
-        int64_t tot = (int64_t)B * Nk * 2 * C;
+        int64_t tot = (int64_t)B * Nk * 2 * C / 8;
         int fb = (int)(cdiv(tot, 256) < 4096 ? cdiv(tot, 256) : 4096);
         hipLaunchKernelGGL((attn_bwd_finish_kernel<bf16>), dim3(fb), dim3(256), 0, stream, dks, dvs, (bf16*)dkv, (int64_t)2 * C, B, Nk, Nkp, heads, D, C, ns);
         SS_LAUNCH_CHECK();
