@@ -73,6 +73,13 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ col, 
     const unsigned row = blockIdx.x, b = row / (unsigned)H, iy = row - b * H;
     const unsigned ix = fdiv(idx, dchunks), c = (idx - ix * chunks) * 8;
     const int64_t kkC = (int64_t)k * k * C;
+    if (k == s && pad == 0) {                              // non-overlapping patches (the MiT spatial-reduction conv): a pure permutation
+        const unsigned oy = fdiv(iy, ds), ox = fdiv(ix, ds), ky = iy - oy * s, kx = ix - ox * s;
+        F8 v = zero8();
+        if (oy < (unsigned)ho && ox < (unsigned)wo) v = load8(col + (((int64_t)b * ho + oy) * wo + ox) * kkC + (int64_t)(ky * k + kx) * C + c);
+        store8(dx + ((int64_t)row * W + ix) * C + c, v);
+        return;
+    }
     F8 acc = zero8();
     for (int ky = 0; ky < k; ++ky) {
         const int ty = (int)iy + pad - ky;
