@@ -397,7 +397,7 @@ def main():
                                   f'(fwd + OHEM-CE + confusion matrix + bwd + grad all-reduce + AdaBound), {a.size}x{a.size}',
                       'per_gpu_batch': a.batch, 'global_batch': a.batch * world, 'parallelism': f'dp{world}',
                       'weights': 'deterministic random init'},
-           'loss': float(loss), 'mIoU': float(cm['mIoU']), 'peak_mem_gib': torch.cuda.max_memory_allocated() / 2 ** 30}
+           'loss': float(loss.detach()), 'mIoU': float(cm['mIoU']), 'peak_mem_gib': torch.cuda.max_memory_allocated() / 2 ** 30}
     if roof is not None:
         res['roofline'] = roof
     if table is not None:                                        # the rate with the optimizer step excluded, beside `value`
