@@ -143,6 +143,26 @@ def gen_head(training):
     np.savez_compressed(os.path.join(HERE, f'lawin_e128_{tag}.npz'), **save)
 
 
+def gen_head_e256():
+    """LawinHead with embed_dim 256 (SURVEY 8c asks for E = 128 and 256), eval mode, 2 x 128 x 128 tiles: logits and feature gradients."""
+    chans = [32, 64, 160, 256]
+    head = det_fill_(LawinHead(chans, 256, 6)).eval()
+    feats = [det_input(f'head256.f{i}', (2, c, 32 >> i, 32 >> i), -1, 1).requires_grad_(True) for i, c in enumerate(chans)]
+    sd = grad_sd(detached_sd(head))
+    out = head(feats)
+    proj = det_input('head256.proj', out.shape, -1, 1)
+    (out * proj).sum().backward()
+    ofe = [f.detach().clone().requires_grad_(True) for f in feats]
+    oout = olawin.lawin_head(sd, ofe, training=False)
+    (oout * proj).sum().backward()
+    check('head256.out', oout, out)
+    save = {'out': np_(out)}
+    for i in range(4):
+        check(f'head256.dfeat{i}', ofe[i].grad, feats[i].grad, 5e-5)
+        save[f'dfeat{i}'] = np_(feats[i].grad)
+    np.savez_compressed(os.path.join(HERE, 'lawin_e256_eval.npz'), **save)
+
+
 def gen_segmentor():
     """MiT-B0 + LawinHead(128, 6) + bilinear x4, eval, 2x3x128x128: fp32 and bf16-autocast logits."""
     enc = det_fill_(SegFormer('B0')).eval()
@@ -289,7 +309,7 @@ def gen_dnet():
 
 if __name__ == '__main__':
     only = sys.argv[1:]
-    gens = {'mit': gen_mit, 'head_eval': lambda: gen_head(False), 'head_train': lambda: gen_head(True), 'segmentor': gen_segmentor,
+    gens = {'mit': gen_mit, 'head_eval': lambda: gen_head(False), 'head_train': lambda: gen_head(True), 'head_e256': gen_head_e256, 'segmentor': gen_segmentor,
             'losses': gen_losses, 'convnext': gen_convnext, 'dnet': gen_dnet}
     for fn in [g for n, g in gens.items() if not only or n in only]:
         fn()

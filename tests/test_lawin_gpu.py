@@ -77,6 +77,30 @@ def test_lawin_head_fp32_matches_reference_golden(golden_dir, training):
                 assert rel(sd[k[6:]].float(), g[k].astype(np.float32)) < 1e-4, k
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_lawin_head_e256_matches_reference_golden(golden_dir, dtype):
+    """embed_dim 256 (heads 64 / 16 / 4 with d = 2 / 8 / 32: the VALU window-attention kernels and the d = 32 MFMA one), eval mode."""
+    from semseg_amd.lawin import LawinHead
+    from semseg_amd.runtime import set_compute_dtype
+    g = np.load(os.path.join(golden_dir, 'lawin_e256_eval.npz'))
+    head = det_fill_(LawinHead(CH, 256, 6)).cuda().eval()
+    feats = [det_input(f'head256.f{i}', (2, c, 32 >> i, 32 >> i), -1, 1).cuda().requires_grad_(True) for i, c in enumerate(CH)]
+    set_compute_dtype(dtype)
+    try:
+        out = head(feats)
+        (out.float() * det_input('head256.proj', out.shape, -1, 1).cuda()).sum().backward()
+    finally:
+        set_compute_dtype(None)
+    if dtype == torch.float32:
+        assert rel(out, g['out']) < 1e-4
+        for i in range(4):
+            assert rel(feats[i].grad, g[f'dfeat{i}']) < 3e-4, i
+    else:
+        assert rel_l2(out, g['out']) < 2e-2
+        for i in range(4):
+            assert rel_l2(feats[i].grad, g[f'dfeat{i}']) < 2e-2, i
+
+
 def test_lawin_head_bf16_matches_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, 'lawin_e128_train.npz'))
     head, feats, out = _head_run(True, torch.bfloat16)

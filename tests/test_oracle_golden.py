@@ -57,6 +57,18 @@ def test_lawin_head(golden_dir, training):
             assert rel(sd[k[6:]].float(), g[k].astype(np.float32)) < 1e-5, k
 
 
+def test_lawin_head_e256(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'lawin_e256_eval.npz'))
+    chans = [32, 64, 160, 256]
+    sd = grad_sd(det_state_dict(shapes.lawin_shapes(chans, 256, 6)))
+    feats = [det_input(f'head256.f{i}', (2, c, 32 >> i, 32 >> i), -1, 1).requires_grad_(True) for i, c in enumerate(chans)]
+    out = olawin.lawin_head(sd, feats, training=False)
+    (out * det_input('head256.proj', out.shape, -1, 1)).sum().backward()
+    assert rel(out.detach(), g['out']) < 2e-5
+    for i in range(4):
+        assert rel(feats[i].grad, g[f'dfeat{i}']) < 5e-5
+
+
 def test_segmentor_and_ohem(golden_dir):
     g = np.load(os.path.join(golden_dir, 'segmentor_b0_e128_128.npz'))
     sd_e = det_state_dict(shapes.mit_shapes('B0', 3))
