@@ -388,7 +388,7 @@ def main():
             dist.destroy_process_group()
         return
     ms = 1e3 * dt / a.steps
-    res = {'metric': 'train images/sec @1024x1024 (DNet ConvNeXt-T)' if a.workload == 'dnet' else 'train images/sec @1024x1024 (MiT-B2+Lawin)', 'value': a.batch * world * a.steps / dt, 'unit': 'images/s',
+    res = {'metric': f'train images/sec @{a.size}x{a.size} (DNet ConvNeXt-T)' if a.workload == 'dnet' else f'train images/sec @{a.size}x{a.size} (MiT-{a.variant}+Lawin)', 'value': a.batch * world * a.steps / dt, 'unit': 'images/s',
            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
            'config': {'workload': (f'configs[2] per-GPU step: DNet(ConvNeXt-T + Decoder(embed 256), 6 cls) training step (fwd + Dice + confusion '
