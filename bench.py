@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--output', default='logits', choices=['logits', 'class_map', 'class_map_unfused'],
                     help='topformer: what a step hands over -- full-size logits (the model forward), the uint8 class map of '
                          'predict.py (fused resize + arg-max), or forward followed by the separate class-map kernel')
+    ap.add_argument('--loss', default='ohem_ce', choices=['ohem_ce', 'ce_dice'], help='mit_lawin: OHEM-CE (configs[1]) or OHEM-CE + Dice on the softmax (configs[4])')
     ap.add_argument('--embed', type=int, default=512)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--size', type=int, default=1024)
@@ -339,7 +340,13 @@ def main():
     flat = FlatParams(net)
     reducer = GradReducer(flat)
     opt = AdaBound(flat, lr=1e-3, final_lr=0.1)
-    crit = DiceLoss(0.5, False, 6) if a.workload == 'dnet' else OhemCrossEntropyLoss(0, 0.7, 0.1)
+    if a.workload == 'dnet':
+        crit = DiceLoss(0.5, False, 6)
+    elif a.loss == 'ce_dice':
+        from semseg_amd.loss import OhemCEDiceLoss
+        crit = OhemCEDiceLoss(6, 0, 0.7, 0.1)
+    else:
+        crit = OhemCrossEntropyLoss(0, 0.7, 0.1)
     met = SegmentationMetrics(6, ignore_index=0).to(dev)
     x, lab = synthetic_batch(a.batch, a.size, rank, dev)
 
@@ -378,7 +385,7 @@ def main():
         if rank == 0:
             table = kernel_table(trace)
             # the committed PMC traffic figure was collected on the default headline configuration only
-            default_cfg = a.variant == 'B2' and a.embed == 512 and a.batch == 16 and a.size == 1024 and a.dtype == 'bf16'
+            default_cfg = a.loss == 'ohem_ce' and a.variant == 'B2' and a.embed == 512 and a.batch == 16 and a.size == 1024 and a.dtype == 'bf16'
             roof = roofline_from_table(table, traffic_ok=default_cfg)
             if a.shapes:
                 shape_table(trace)
@@ -394,7 +401,7 @@ def main():
            'config': {'workload': (f'configs[2] per-GPU step: DNet(ConvNeXt-T + Decoder(embed 256), 6 cls) training step (fwd + Dice + confusion '
                                    f'matrix + bwd + grad all-reduce + AdaBound), {a.size}x{a.size}') if a.workload == 'dnet' else
                                   f'configs[1]: SegFormer MiT-{a.variant} + LawinHead({a.embed}, 6 cls) training step '
-                                  f'(fwd + OHEM-CE + confusion matrix + bwd + grad all-reduce + AdaBound), {a.size}x{a.size}',
+                                  f'(fwd + {"OHEM-CE + Dice" if a.loss == "ce_dice" else "OHEM-CE"} + confusion matrix + bwd + grad all-reduce + AdaBound), {a.size}x{a.size}',
                       'per_gpu_batch': a.batch, 'global_batch': a.batch * world, 'parallelism': f'dp{world}',
                       'weights': 'deterministic random init'},
            'loss': float(loss.detach()), 'mIoU': float(cm['mIoU']), 'peak_mem_gib': torch.cuda.max_memory_allocated() / 2 ** 30}

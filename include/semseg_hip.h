@@ -208,6 +208,14 @@ int ss_dice_sums(int dtype, const void* probs, int64_t sn, int64_t sc, int64_t s
                  int C, int H, int W, float* sums, float* workspace, int64_t ws_bytes, hipStream_t stream);
 int ss_dice_bwd(int dtype, const int64_t* labels, const float* coef_hit, const float* coef_all, const float* gout, void* dprobs,
                 int64_t on, int64_t oc, int64_t oh, int64_t ow, int B, int C, int H, int W, hipStream_t stream);
+/* ---- torch.nn.Softmax2d (modules/layers.py:41) for logits with no fused producer: the probabilities DiceLoss takes when MiT + Lawin
+ * trains with OHEM-CE + Dice (BASELINE configs[4]).  All tensors [B][C][H][W] with element strides (n, c, h, w).
+ * backward: dx[c] = y[c] * (dy[c] - sum_k dy[k] y[k]). */
+int ss_softmax2d_fwd(int dtype, const void* x, int64_t xn, int64_t xc, int64_t xh, int64_t xw, void* y, int64_t yn, int64_t yc,
+                     int64_t yh, int64_t yw, int B, int C, int H, int W, hipStream_t stream);
+int ss_softmax2d_bwd(int dtype, const void* y, int64_t yn, int64_t yc, int64_t yh, int64_t yw, const void* dy, int64_t gn, int64_t gc,
+                     int64_t gh, int64_t gw, void* dx, int64_t xn, int64_t xc, int64_t xh, int64_t xw, int B, int C, int H, int W,
+                     hipStream_t stream);
 /* ---- SegmentationMetrics.update (helper/metrics.py:90-95 + torchmetrics ConfusionMatrix): cm[target][argmax] += 1, int64, exact;
  * first maximum wins ties. */
 int ss_confusion_update(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,

@@ -362,6 +362,37 @@ __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ lo
     }
 }
 
+// ------------------------------------------------------------------ Softmax2d (torch.nn.Softmax2d of modules/layers.py:41; the
+// probabilities DiceLoss takes, loss/seg_loss.py:82-99) for logits that have no fused producer: BASELINE configs[4] trains
+// MiT + Lawin with OHEM-CE on the logits AND Dice on their softmax.  A thread owns one pixel; exponentials in fp32.
+//   forward : y[c] = exp(x[c] - max) / sum        backward: dx[c] = y[c] * (dy[c] - sum_k dy[k] y[k])
+template <typename T>
+__global__ __launch_bounds__(256) void softmax2d_fwd_kernel(const T* __restrict__ x, Strides sx, T* __restrict__ y, Strides sy, int64_t npix,
+                                                            int H, int W, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const T* p = x + pix_off(i, H, W, sx);
+        T* q = y + pix_off(i, H, W, sy);
+        float m = to_f(p[0]);
+        for (int c = 1; c < C; ++c) m = fmaxf(m, to_f(p[c * sx.c]));
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += expf(to_f(p[c * sx.c]) - m);
+        const float inv = 1.f / sum;
+        for (int c = 0; c < C; ++c) q[c * sy.c] = from_f<T>(expf(to_f(p[c * sx.c]) - m) * inv);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void softmax2d_bwd_kernel(const T* __restrict__ y, Strides sy, const T* __restrict__ dy, Strides sd,
+                                                            T* __restrict__ dx, Strides sx, int64_t npix, int H, int W, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const T* p = y + pix_off(i, H, W, sy);
+        const T* g = dy + pix_off(i, H, W, sd);
+        T* q = dx + pix_off(i, H, W, sx);
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) dot = fmaf(to_f(g[c * sd.c]), to_f(p[c * sy.c]), dot);
+        for (int c = 0; c < C; ++c) q[c * sx.c] = from_f<T>(to_f(p[c * sy.c]) * (to_f(g[c * sd.c]) - dot));
+    }
+}
+
 // ------------------------------------------------------------------ prediction writer / evaluation script
 // helper/callbacks.py:52-54: prediction.softmax(dim=1).argmax(dim=1) -> class map.  softmax is increasing in the logit, so the
 // arg-max is taken on the logits themselves; the first maximum wins (torch.argmax); a pixel that holds a NaN gets class 0
@@ -575,6 +606,29 @@ extern "C" int ss_confusion_labels_u8(const uint8_t* truth, const uint8_t* pred,
     const int copies = cm_copies(C);
     hipLaunchKernelGGL(confusion_labels_kernel, dim3(nblk(cdiv(n, 4), 512)), dim3(256), (size_t)C * C * copies * sizeof(unsigned), stream, truth, pred,
                        valid, lut, (unsigned long long*)cm, n, C, copies);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// x, y (and dy, dx): [B][C][H][W] with element strides, any dense layout
+extern "C" int ss_softmax2d_fwd(int dtype, const void* x, int64_t xn, int64_t xc, int64_t xh, int64_t xw, void* y, int64_t yn, int64_t yc,
+                                int64_t yh, int64_t yw, int B, int C, int H, int W, hipStream_t stream) {
+    SS_CHECK(x && y && B > 0 && C > 0 && H > 0 && W > 0, "ss_softmax2d_fwd: bad arguments");
+    const int64_t npix = (int64_t)B * H * W;
+    Strides sx{xn, xc, xh, xw}, sy{yn, yc, yh, yw};
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((softmax2d_fwd_kernel<T>), dim3(nblk(npix, 16384)), dim3(256), 0, stream, (const T*)x, sx, (T*)y, sy, npix,
+                                          H, W, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_softmax2d_bwd(int dtype, const void* y, int64_t yn, int64_t yc, int64_t yh, int64_t yw, const void* dy, int64_t gn, int64_t gc,
+                                int64_t gh, int64_t gw, void* dx, int64_t xn, int64_t xc, int64_t xh, int64_t xw, int B, int C, int H, int W,
+                                hipStream_t stream) {
+    SS_CHECK(y && dy && dx && B > 0 && C > 0 && H > 0 && W > 0, "ss_softmax2d_bwd: bad arguments");
+    const int64_t npix = (int64_t)B * H * W;
+    Strides sy{yn, yc, yh, yw}, sd{gn, gc, gh, gw}, sx{xn, xc, xh, xw};
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((softmax2d_bwd_kernel<T>), dim3(nblk(npix, 16384)), dim3(256), 0, stream, (const T*)y, sy, (const T*)dy, sd,
+                                          (T*)dx, sx, npix, H, W, C));
     SS_LAUNCH_CHECK();
     return 0;
 }

@@ -124,3 +124,40 @@ class DiceLoss(Module):
         if preds.shape[1] != self.num_classes or not torch.equal(self.class_ids, torch.arange(self.num_classes)):
             raise NotImplementedError('DiceLoss: class_ids must be arange(num_classes) == channels of preds')
         return _DiceFn.apply(preds, labels.contiguous(), 'tversky', float(self.delta), 0.0, bool(self.weighted))
+
+
+class _Softmax2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.softmax2d_fwd(x.detach())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.softmax2d_bwd(y, dy if dy.dtype == y.dtype else dy.to(y.dtype))
+
+
+class Softmax2d(Module):
+    """torch.nn.Softmax2d (the last layer of modules/layers.py:25-43) on the HIP path, for logits that have no fused producer."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        return _Softmax2dFn.apply(x)
+
+
+class OhemCEDiceLoss(Module):
+    """OHEM cross-entropy on the logits plus Tversky / Dice on their softmax: the "CE + Dice" objective BASELINE configs[4] names
+    for MiT-B5 + Lawin.  The reference holds the two terms as separate classes (loss/seg_loss.py:59-167) and its networks that feed
+    DiceLoss end in Softmax2d; this is their sum, ``ce_weight * OhemCrossEntropyLoss + dice_weight * DiceLoss(Softmax2d(preds))``."""
+
+    def __init__(self, num_classes: int, ignore_index: int, threshold: float = 0.7, min_kept: float = 0.1, delta: float = 0.5,
+                 weighted: bool = False, ce_weight: float = 1.0, dice_weight: float = 1.0):
+        super().__init__()
+        self.ce = OhemCrossEntropyLoss(ignore_index, threshold, min_kept)
+        self.dice = DiceLoss(delta, weighted, num_classes)
+        self.softmax = Softmax2d()
+        self.ce_weight, self.dice_weight = ce_weight, dice_weight
+
+    def forward(self, preds: Tensor, targets: Tensor) -> Tensor:
+        return self.ce_weight * self.ce(preds, targets) + self.dice_weight * self.dice(self.softmax(preds), targets)

@@ -616,6 +616,30 @@ def confusion_update(logits, labels, cm):
     return cm
 
 
+def _like_channels_last(x):
+    B, C, H, W = x.shape
+    return torch.empty((B, H, W, C), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+
+
+def softmax2d_fwd(x):
+    """[B, C, H, W] logits (any dense layout) -> probabilities over C, stored channels-last (returned as its NCHW view)."""
+    _dev(x)
+    (B, C, H, W), sx = _nchw(x, 'x')
+    y = _like_channels_last(x)
+    check(lib().ss_softmax2d_fwd(dt(x), _p(x), *sx, _p(y), *y.stride(), B, C, H, W, _stream()))
+    return y
+
+
+def softmax2d_bwd(y, dy):
+    _dev(y)
+    (B, C, H, W), sy = _nchw(y, 'y')
+    if dy.shape != y.shape or dy.dtype != y.dtype:
+        raise ValueError('softmax2d_bwd: dy must match y')
+    dx = _like_channels_last(y)
+    check(lib().ss_softmax2d_bwd(dt(y), _p(y), *sy, _p(dy), *dy.stride(), _p(dx), *dx.stride(), B, C, H, W, _stream()))
+    return dx
+
+
 def class_map(prediction):
     """[B, C, H, W] logits (any strides) -> uint8 [B, H, W]: prediction.softmax(1).argmax(1) of helper/callbacks.py:52-54."""
     dev = _dev(prediction)

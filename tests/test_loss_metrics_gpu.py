@@ -135,3 +135,40 @@ def test_confusion_matrix_full_size_checksum():
     assert int(cm.sum()) == B * S * S
     assert torch.equal(cm.sum(1), torch.bincount(lab.reshape(-1), minlength=C))
     assert torch.equal(cm.sum(0), torch.bincount(logits.float().argmax(1).reshape(-1), minlength=C))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 6, 33, 47), (1, 19, 8, 8), (3, 2, 5, 64)])
+def test_softmax2d_fwd_bwd_vs_torch(dtype, shape):
+    from semseg_amd.loss import Softmax2d
+    x = det_input('sm.x', shape, -4, 4)
+    w = det_input('sm.w', shape, -1, 1)
+    xr = x.to(dtype).float().clone().requires_grad_(True)
+    ref = torch.nn.Softmax2d()(xr)
+    (ref * w).sum().backward()
+    for layout in ('nchw', 'nhwc'):
+        xg = x.detach().to(dtype).cuda()
+        if layout == 'nhwc':
+            xg = xg.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        xg.requires_grad_(True)
+        y = Softmax2d()(xg)
+        (y.float() * w.cuda()).sum().backward()
+        tol = 1e-6 if dtype == torch.float32 else 1e-2
+        assert float((y.detach().float().cpu() - ref.detach()).abs().max()) < tol
+        assert float((xg.grad.float().cpu() - xr.grad).abs().max()) < tol * max(1.0, float(xr.grad.abs().max()))
+
+
+def test_ohem_ce_plus_dice_vs_oracle():
+    """BASELINE configs[4] objective: OHEM-CE(logits) + Dice(softmax(logits)), loss and logit gradient vs the CPU oracle (fp32 1e-4)."""
+    from oracle.losses import OhemCE, tversky_dice
+    from semseg_amd.loss import OhemCEDiceLoss
+    logits = det_input('cd.logits', (2, 6, 48, 40), -3, 3)
+    lab = det_labels('cd.lab', (2, 48, 40), 6, cell=4)
+    lo = logits.clone().requires_grad_(True)
+    want = OhemCE(0, 0.7, 0.1)(lo, lab) + tversky_dice(torch.softmax(lo, dim=1), lab, 6, 0.5, False)
+    want.backward()
+    lg = logits.cuda().permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).requires_grad_(True)
+    got = OhemCEDiceLoss(6, 0, 0.7, 0.1)(lg, lab.cuda())
+    got.backward()
+    assert rel(got, want) < 1e-5
+    assert rel(lg.grad, lo.grad) < 1e-4
