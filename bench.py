@@ -279,7 +279,7 @@ def topformer_inference(a, world, rank, dev):
     trace, _lib.TRACE = _lib.TRACE, None
     if rank == 0:
         table = kernel_table(trace)
-        res = {'metric': 'inference images/sec @2048x2048 (TopFormer-B)', 'value': batch * world * a.steps / dt, 'unit': 'images/s', 'n_gpus': world,
+        res = {'metric': f'inference images/sec @{size}x{size} (TopFormer-B)', 'value': batch * world * a.steps / dt, 'unit': 'images/s', 'n_gpus': world,
                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
                'config': {'workload': f'configs[3]: TopFormer-B + {a.head} head inference, {size}x{size}, output {a.output}', 'per_gpu_batch': batch,
