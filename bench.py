@@ -30,8 +30,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (no sparsity)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='mit_lawin', choices=['mit_lawin', 'dnet', 'topformer'],
                     help="mit_lawin = BASELINE configs[1] (the headline); dnet = configs[2] per-GPU step (DNet-T, embed 256, batch 8, Dice loss)")
     ap.add_argument('--variant', default='B2')
