@@ -21,13 +21,9 @@ def step():
     flat.zero_grad(); out = net(x); loss = crit(out, lab); met.update(out, lab); loss.backward(); opt.step(red.wait())
 for _ in range(3): step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step()
-torch.cuda.synchronize()
-cnt = collections.Counter()
-for e in prof.events():
-    if e.name in ('aten::copy_', 'aten::fill_', 'aten::zero_', 'aten::cat', 'aten::mul', 'aten::add', 'aten::add_', 'aten::sum', 'aten::clone', 'aten::_to_copy', 'aten::rand', 'aten::div', 'aten::contiguous'):
-        where = next((f for f in e.stack if 'semseg_amd' in f or 'bench.py' in f), e.stack[0] if e.stack else '?')
-        cnt[(e.name, where.split('/')[-1][:90])] += 1
-for (name, where), n in cnt.most_common(40):
-    print(f'{n:4d} {name:16s} {where}')
+    torch.cuda.synchronize()
+rows = sorted(prof.key_averages(), key=lambda e: -e.count)
+for e in rows[:45]:
+    print(f'{e.count:5d}  {e.key[:100]}')
