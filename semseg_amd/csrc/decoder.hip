@@ -70,6 +70,40 @@ __global__ __launch_bounds__(256) void decoder_combine_fwd_kernel(const T* __res
     }
 }
 
+// the same with the channel count known at compile time (DNet: oc = 12, or 6): the BatchNorm affine is folded into one scale and
+// shift per channel held in registers, and a pixel's oc products leave as 8-byte stores instead of oc 2-byte ones
+template <typename T, int OC>
+__global__ __launch_bounds__(256) void decoder_combine_fwd_fixed_kernel(const T* __restrict__ z9, const T* __restrict__ bs, const float* __restrict__ dbias,
+        const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ prod, DecGeom g) {
+    float db[OC], mean[OC], rstd[OC], gm[OC], bt[OC];
+#pragma unroll
+    for (int o = 0; o < OC; ++o) { db[o] = dbias[o]; mean[o] = stats[o]; rstd[o] = stats[OC + o]; gm[o] = gamma[o]; bt[o] = beta[o]; }
+    const int64_t total = (int64_t)g.B * g.Hd * g.Wd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % g.Wd); int64_t q = i / g.Wd; const int y = (int)(q % g.Hd); const int64_t b = q / g.Hd;
+        const int64_t ps = (b * g.H4 + (y >> 2)) * g.W4 + (x >> 2);
+        const int dy = y & 3, dx = x & 3;
+        const bool tap = dy != 3 && dx != 3;                          // stride 4 > kernel 3: the gaps hold the bias only
+        const T* zp = z9 + ps * g.ld9 + dy * 3 + dx;
+        const T* bp = bs + ps * g.ldb;
+        union { T v[OC]; unsigned long long w[(OC * sizeof(T)) / 8]; } out;
+#pragma unroll
+        for (int o = 0; o < OC; ++o) {
+            const float ap = tap ? db[o] + to_f(zp[o * 9]) : db[o];
+            const float a = fmaxf((ap - mean[o]) * rstd[o] * gm[o] + bt[o], 0.f);
+            out.v[o] = from_f<T>(a * to_f(bp[o]));
+        }
+        T* dst = prod + i * OC;
+        if ((((uintptr_t)dst) & 7) == 0) {
+#pragma unroll
+            for (int k = 0; k < (int)((OC * sizeof(T)) / 8); ++k) ((unsigned long long*)dst)[k] = out.w[k];
+        } else {
+#pragma unroll
+            for (int o = 0; o < OC; ++o) dst[o] = out.v[o];
+        }
+    }
+}
+
 // pass 1 of the backward: per channel sum g and sum g * xhat, g = dprod * b * [a > 0];  partial[blk][2*oc]
 template <typename T>
 __global__ __launch_bounds__(256) void decoder_combine_bwd_stats_kernel(const T* __restrict__ dprod, const T* __restrict__ z9, const T* __restrict__ bs,
@@ -253,6 +287,39 @@ __global__ __launch_bounds__(256) void terminator_fwd_kernel(const T* __restrict
     }
 }
 
+// DNet's own channel counts known at compile time (nc = 6 classes, oc = 6 or 12): the generic kernel above walks DEC_MAXC
+// predicated slots per pixel; here the product row is read as 4-byte pairs and everything unrolls to nc * oc fmas.
+template <typename T, int NC, int OC>
+__global__ __launch_bounds__(256) void terminator_fwd_fixed_kernel(const T* __restrict__ prod, const float* __restrict__ wt, const float* __restrict__ bt,
+        T* __restrict__ probs, TermGeom g) {
+    __shared__ float ws[NC * OC + NC];
+    for (int t = threadIdx.x; t < NC * OC + NC; t += blockDim.x) ws[t] = t < NC * OC ? wt[t] : bt[t - NC * OC];
+    __syncthreads();
+    const int64_t total = (int64_t)g.B * g.H * g.W, hw = (int64_t)g.H * g.W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % g.W); int64_t q = i / g.W; const int Y = (int)(q % g.H); const int64_t b = q / g.H;
+        const int sy = nearest_src(Y, g.sy, g.Hd), sx = nearest_src(X, g.sx, g.Wd);
+        const T* pr = prod + ((b * g.Hd + sy) * g.Wd + sx) * OC;
+        float pv[OC], lg[NC];
+#pragma unroll
+        for (int o = 0; o < OC; ++o) pv[o] = to_f(pr[o]);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float s = ws[NC * OC + c];
+#pragma unroll
+            for (int o = 0; o < OC; ++o) s += ws[c * OC + o] * pv[o];
+            lg[c] = s; mx = fmaxf(mx, s);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { lg[c] = __expf(lg[c] - mx); den += lg[c]; }
+        const float inv = 1.f / den;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) probs[(b * NC + c) * hw + (int64_t)Y * g.W + X] = from_f<T>(lg[c] * inv);
+    }
+}
+
 // one thread per SOURCE pixel of the (Hd,Wd) map: softmax backward is linear in dprobs, so the destination pixels that share the
 // source are summed first.  dprod written; dW (nc*oc) and db (nc) as per-workgroup partials [blk][nc*oc + nc].
 template <typename T>
@@ -420,8 +487,16 @@ extern "C" int ss_decoder_combine_fwd(int dtype, const void* z9, int64_t ld9, co
                                       const float* gamma, const float* beta, void* prod, int B, int H4, int W4, int oc, hipStream_t stream) {
     SS_CHECK(z9 && bs && dbias && stats && gamma && beta && prod, "ss_decoder_combine_fwd: null pointer");
     DecGeom g; if (dec_geom(&g, B, H4, W4, oc, ld9, ldb, "ss_decoder_combine_fwd")) return -1;
-    SS_DISPATCH(dtype, hipLaunchKernelGGL((decoder_combine_fwd_kernel<T>), dim3(dec_blocks((int64_t)B * g.Hd * g.Wd, 32768)), dim3(256), 0, stream,
-                                          (const T*)z9, (const T*)bs, dbias, stats, gamma, beta, (T*)prod, g));
+    dim3 grid(dec_blocks((int64_t)B * g.Hd * g.Wd, 32768));
+    if (oc == 12)
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((decoder_combine_fwd_fixed_kernel<T, 12>), grid, dim3(256), 0, stream, (const T*)z9, (const T*)bs, dbias, stats,
+                                              gamma, beta, (T*)prod, g));
+    else if (oc == 8)
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((decoder_combine_fwd_fixed_kernel<T, 8>), grid, dim3(256), 0, stream, (const T*)z9, (const T*)bs, dbias, stats,
+                                              gamma, beta, (T*)prod, g));
+    else
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((decoder_combine_fwd_kernel<T>), grid, dim3(256), 0, stream, (const T*)z9, (const T*)bs, dbias, stats, gamma,
+                                              beta, (T*)prod, g));
     SS_LAUNCH_CHECK();
     return 0;
 }
@@ -467,8 +542,13 @@ extern "C" int ss_terminator_fwd(int dtype, const void* prod, const float* wt, c
                                  int oc, int nc, hipStream_t stream) {
     SS_CHECK(prod && wt && bt && probs, "ss_terminator_fwd: null pointer");
     TermGeom g; if (term_geom(&g, B, Hd, Wd, H, W, oc, nc, "ss_terminator_fwd")) return -1;
-    SS_DISPATCH(dtype, hipLaunchKernelGGL((terminator_fwd_kernel<T>), dim3(dec_blocks((int64_t)B * H * W, 32768)), dim3(256), 0, stream, (const T*)prod,
-                                          wt, bt, (T*)probs, g));
+    dim3 grid(dec_blocks((int64_t)B * H * W, 32768));
+    if (nc == 6 && oc == 12)
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((terminator_fwd_fixed_kernel<T, 6, 12>), grid, dim3(256), 0, stream, (const T*)prod, wt, bt, (T*)probs, g));
+    else if (nc == 6 && oc == 6)
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((terminator_fwd_fixed_kernel<T, 6, 6>), grid, dim3(256), 0, stream, (const T*)prod, wt, bt, (T*)probs, g));
+    else
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((terminator_fwd_kernel<T>), grid, dim3(256), 0, stream, (const T*)prod, wt, bt, (T*)probs, g));
     SS_LAUNCH_CHECK();
     return 0;
 }
