@@ -268,8 +268,15 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict_
     if (threadIdx.x == 0) { psum[blockIdx.x] = ss[0]; pcnt[blockIdx.x] = sn[0]; }
 }
 __global__ void ce_finalize_kernel(OhemCtl* ctl, const float* __restrict__ psum, const unsigned* __restrict__ pcnt, int nb, float* __restrict__ loss) {
+    // 256 threads, thread t adds partials t, t + 256, ...; fixed-order tree in LDS (was one thread walking all nb partials: 64 us)
+    __shared__ double ss[256]; __shared__ long long sn[256];
     double s = 0.0; long long n = 0;
-    for (int b = 0; b < nb; ++b) { s += psum[b]; n += pcnt[b]; }
+    for (int b = threadIdx.x; b < nb; b += 256) { s += psum[b]; n += pcnt[b]; }
+    ss[threadIdx.x] = s; sn[threadIdx.x] = n;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) { ss[threadIdx.x] += ss[threadIdx.x + o]; sn[threadIdx.x] += sn[threadIdx.x + o]; } __syncthreads(); }
+    if (threadIdx.x != 0) return;
+    s = ss[0]; n = sn[0];
     ctl->kept = n; ctl->loss_sum = (float)s;
     loss[0] = (float)(s / (double)n);            // mean over an empty selection is NaN, as torch
 }
@@ -520,7 +527,7 @@ extern "C" int ss_ohem_ce_fwd(int dtype, const void* logits, int64_t sn, int64_t
     hipLaunchKernelGGL(ohem_threshold_kernel, dim3(1), dim3(256), 0, stream, ctl, vkey, prob, npix, thr_state);
     const int rb = (int)(cdiv(npix, 1024) < CE_REDUCE_BLOCKS ? cdiv(npix, 1024) : CE_REDUCE_BLOCKS);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(rb), dim3(256), 0, stream, prob, nll, vkey, ctl, npix, psum, pcnt);
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, stream, ctl, psum, pcnt, rb, loss);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, stream, ctl, psum, pcnt, rb, loss);
     SS_LAUNCH_CHECK();
     SS_HIP(hipMemcpyAsync(ctl_out, ctl, 256, hipMemcpyDeviceToDevice, stream));
     return 0;
