@@ -208,6 +208,9 @@ int ss_dice_sums(int dtype, const void* probs, int64_t sn, int64_t sc, int64_t s
                  int C, int H, int W, float* sums, float* workspace, int64_t ws_bytes, hipStream_t stream);
 int ss_dice_bwd(int dtype, const int64_t* labels, const float* coef_hit, const float* coef_all, const float* gout, void* dprobs,
                 int64_t on, int64_t oc, int64_t oh, int64_t ow, int B, int C, int H, int W, hipStream_t stream);
+/* helper/weights.py:18-22 (class_weights: the label frequencies; the reference compares every pixel with every class id in a
+ * [pixels x classes] boolean matrix): hist[v] += #(labels == v) for v in [0, nbins), int64, exact; other values are not counted. */
+int ss_label_hist(const int64_t* labels, int64_t n, int nbins, int64_t* hist, hipStream_t stream);
 /* ---- torch.nn.Softmax2d (modules/layers.py:41) for logits with no fused producer: the probabilities DiceLoss takes when MiT + Lawin
  * trains with OHEM-CE + Dice (BASELINE configs[4]).  All tensors [B][C][H][W] with element strides (n, c, h, w).
  * backward: dx[c] = y[c] * (dy[c] - sum_k dy[k] y[k]). */

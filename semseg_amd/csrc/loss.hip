@@ -369,6 +369,27 @@ __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ lo
     }
 }
 
+// ------------------------------------------------------------------ label histogram: hist[v] += #(labels == v), v in [0, nbins)
+// helper/weights.py:18-27 builds a [pixels x classes] boolean matrix to count the labels; one pass over the int64 labels with
+// per-workgroup LDS bins (lane l counts in copy l % copies) and one 64-bit global add per non-empty bin.  Exact.
+__global__ __launch_bounds__(256) void label_hist_kernel(const long long* __restrict__ labels, unsigned long long* __restrict__ hist,
+                                                         int64_t n, int nbins, int copies) {
+    extern __shared__ unsigned bins[];
+    for (int i = threadIdx.x; i < nbins * copies; i += blockDim.x) bins[i] = 0;
+    __syncthreads();
+    unsigned* mine = bins + (threadIdx.x % copies) * nbins;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long v = labels[i];
+        if (v >= 0 && v < nbins) atomicAdd(&mine[(int)v], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
+        unsigned long long t = 0;
+        for (int k = 0; k < copies; ++k) t += bins[k * nbins + i];
+        if (t) atomicAdd(&hist[i], t);
+    }
+}
+
 // ------------------------------------------------------------------ Softmax2d (torch.nn.Softmax2d of modules/layers.py:41; the
 // probabilities DiceLoss takes, loss/seg_loss.py:82-99) for logits that have no fused producer: BASELINE configs[4] trains
 // MiT + Lawin with OHEM-CE on the logits AND Dice on their softmax.  A thread owns one pixel; exponentials in fp32.
@@ -586,6 +607,16 @@ extern "C" int ss_confusion_update(int dtype, const void* logits, int64_t sn, in
     const int copies = cm_copies(C);
     SS_DISPATCH(dtype, hipLaunchKernelGGL((confusion_kernel<T>), dim3(nblk(npix, 2048)), dim3(256), (size_t)C * C * copies * sizeof(unsigned), stream,
                                           (const T*)logits, s, (const long long*)labels, (unsigned long long*)cm, npix, H, W, C, copies));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// labels: int64 [n]; hist: int64 [nbins], accumulated in place (values outside [0, nbins) are not counted)
+extern "C" int ss_label_hist(const int64_t* labels, int64_t n, int nbins, int64_t* hist, hipStream_t stream) {
+    SS_CHECK(labels && hist && n > 0 && nbins > 0 && nbins <= 4096, "ss_label_hist: bad arguments (1 <= nbins <= 4096)");
+    int copies = 8192 / nbins; copies = copies < 1 ? 1 : (copies > 16 ? 16 : copies);
+    hipLaunchKernelGGL(label_hist_kernel, dim3(nblk(n, 2048)), dim3(256), (size_t)nbins * copies * sizeof(unsigned), stream,
+                       (const long long*)labels, (unsigned long long*)hist, n, nbins, copies);
     SS_LAUNCH_CHECK();
     return 0;
 }

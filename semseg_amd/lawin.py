@@ -17,7 +17,7 @@ from torch import nn, Tensor
 import torch.nn.functional as tnf
 
 from . import ops
-from .runtime import compute_dtype_for, as_tokens_nhwc, deliver_grads
+from .runtime import compute_dtype_for, as_tokens_nhwc, deliver_grads, expect_grads
 from .segformer import w_fwd, w_bwd
 from .shapes import LAWIN_BRANCHES
 
@@ -194,6 +194,7 @@ class LawinHeadFn(torch.autograd.Function):
         Bf = dict(module.named_buffers())
         seg, S = head_forward(P, Bf, (x1, x2, x3, x4), module.embed_dim, module.training, drop_mask)
         ctx.S, ctx.names, ctx.params, ctx.E = S, names, params, module.embed_dim
+        expect_grads(ctx, params, 7)
         B, (H4, W4) = S['B'], S['hw'][0]
         return _nchw_view(seg, B, H4, W4)
 

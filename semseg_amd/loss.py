@@ -51,15 +51,20 @@ class OhemCrossEntropyLoss(Module):
 
 
 def class_weights(x: torch.Tensor, class_ids: torch.Tensor):
-    """helper/weights.py:4-27 from the label histogram kernel (class_ids must be arange(n))."""
-    n = class_ids.numel()
-    lab = x.reshape(1, 1, -1).to(torch.int64).contiguous()
-    dummy = torch.zeros((1, n, 1, lab.shape[-1]), dtype=torch.float32, device=x.device)
-    freq = ops.dice_sums(dummy, lab)[0, :, 2]
-    return _weights_from_freq(freq)
+    """helper/weights.py:4-27: inverse-frequency weights of the classes ``class_ids`` in the label tensor ``x`` (any integer
+    values in 0..4095; an id that never occurs gets weight 0), from one label-histogram pass."""
+    ids = class_ids.reshape(-1).to(device=x.device, dtype=torch.long)
+    if ids.numel() == 0:
+        raise ValueError('class_weights: class_ids is empty')
+    lo, hi = int(ids.min()), int(ids.max())
+    if lo < 0 or hi >= 4096:
+        raise ValueError(f'class_weights: class ids must lie in 0..4095 (got {lo}..{hi})')
+    hist = ops.label_hist(x.reshape(-1).to(torch.int64).contiguous(), hi + 1)
+    return _weights_from_freq(hist[ids].to(torch.float32))
 
 
 def _weights_from_freq(freq):
+    """frequencies (float32; exact below 2^24 per class, as the reference's integer / integer true division rounds) -> weights"""
     w = freq.sum() / (freq.numel() * freq)
     w = torch.where(freq == 0, torch.zeros_like(w), w)
     return w / w.sum()

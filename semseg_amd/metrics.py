@@ -22,26 +22,30 @@ def delete_indices(tensor: torch.Tensor, indices):
     return tensor[mask]
 
 
-def _safe_div(a, b):
-    return torch.where(b != 0, a / torch.where(b != 0, b, torch.ones_like(b)), torch.zeros_like(a))
-
-
 def scores_from_confmat(cm: torch.Tensor):
-    """All derived scores (float32) from an int64 [C, C] matrix (rows = target, cols = prediction)."""
-    cmf = cm.to(torch.float32)
-    tp = cmf.diagonal()
-    fp = cmf.sum(0) - tp
-    fn = cmf.sum(1) - tp
-    absent = (tp + fp + fn) == 0
-    nan = torch.full_like(tp, float('nan'))
-    prec = torch.where(absent, nan, _safe_div(tp, tp + fp))
-    rec = torch.where(absent, nan, _safe_div(tp, tp + fn))
-    f1 = torch.where(absent, nan, _safe_div(2 * tp, 2 * tp + fp + fn))
+    """All derived scores (float32) from an int64 [C, C] matrix (rows = target, cols = prediction).  Sums and differences stay
+    in int64 (exact at any pixel count); only the final ratios are taken in floating point: the statistics are converted once, as
+    torchmetrics' ``_reduce_stat_scores`` does with its integer tp / fp / fn, and divided in float64 so that a count above 2^24 is
+    not rounded before the division; the result is rounded to float32 once."""
+    cm = cm.to(torch.int64)
+    tp = cm.diagonal()
+    fp = cm.sum(0) - tp
+    fn = cm.sum(1) - tp
     union = tp + fp + fn
-    iou = torch.where(union == 0, torch.ones_like(tp), _safe_div(tp, union))      # absent_score = 1.0
-    total = cmf.sum()
-    return {'Precision': prec, 'Recall': rec, 'IoU': iou, 'F1': f1, 'Accuracy': rec.clone(), 'Confusion_Matrix': cm,
-            'mIoU': iou.mean(), 'Global Accuracy': _safe_div(tp.sum(), total)}
+    absent = union == 0
+    f64 = torch.float64
+    nan = torch.full(tp.shape, float('nan'), dtype=f64, device=cm.device)
+
+    def ratio(a, b):
+        a, b = a.to(f64), b.to(f64)
+        return torch.where(b != 0, a / torch.where(b != 0, b, torch.ones_like(b)), torch.zeros_like(a))
+
+    prec = torch.where(absent, nan, ratio(tp, tp + fp)).float()
+    rec = torch.where(absent, nan, ratio(tp, tp + fn)).float()
+    f1 = torch.where(absent, nan, ratio(2 * tp, 2 * tp + fp + fn)).float()
+    iou64 = torch.where(absent, torch.ones_like(nan), ratio(tp, union))                       # absent_score = 1.0
+    return {'Precision': prec, 'Recall': rec, 'IoU': iou64.float(), 'F1': f1, 'Accuracy': rec.clone(), 'Confusion_Matrix': cm,
+            'mIoU': iou64.mean().float(), 'Global Accuracy': ratio(tp.sum(), cm.sum()).float()}
 
 
 class SegmentationMetrics(nn.Module):

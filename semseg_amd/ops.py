@@ -604,6 +604,19 @@ def dice_bwd(probs_like, labels, coef_hit, coef_all, gout):
     return d
 
 
+def label_hist(labels, nbins):
+    """int64 labels (any shape) -> int64 [nbins] counts of the values 0 .. nbins-1."""
+    dev = _dev(labels)
+    if labels.dtype != torch.int64 or not labels.is_contiguous():
+        raise ValueError('label_hist: labels must be a contiguous int64 tensor')
+    if not 0 < nbins <= 4096:
+        raise ValueError('label_hist: 1 <= nbins <= 4096')
+    hist = torch.zeros(nbins, dtype=torch.int64, device=dev)
+    if labels.numel():
+        check(lib().ss_label_hist(_p(labels), labels.numel(), nbins, _p(hist), _stream()))
+    return hist
+
+
 def confusion_update(logits, labels, cm):
     """cm int64 [C, C] += counts of (target, argmax(logits, 1))."""
     _dev(logits)

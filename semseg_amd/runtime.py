@@ -20,7 +20,7 @@ def compute_dtype_for(x):
     if _FORCED is not None:
         return _FORCED
     if torch.is_autocast_enabled():
-        adt = torch.get_autocast_gpu_dtype()
+        adt = torch.get_autocast_dtype('cuda')
         if adt == torch.float16:
             warnings.warn('semseg_amd computes reduced precision in bfloat16 (fp32 accumulation); fp16 autocast is mapped to bf16')
             return torch.bfloat16
@@ -45,6 +45,16 @@ def drop_path_keep(b, drop_prob, dtype, device):
     call, shape and dtype), returned as fp32 [B] for the GEMM epilogue."""
     kp = 1 - drop_prob
     return ops.droppath_keep(torch.rand((b, 1, 1), dtype=dtype, device=device), kp)
+
+
+def expect_grads(ctx, params, first):
+    """Forward-side twin of ``deliver_grads``: tells whoever tracks gradient arrival (engine.GradReducer, through the parameter's
+    ``_ss_grad_expect`` callback) that this graph node will deliver one gradient to each of its parameters, ``params`` being the
+    inputs ``first``, ``first + 1``, ... of the autograd Function whose forward is running."""
+    for i, p in enumerate(params):
+        cb = getattr(p, '_ss_grad_expect', None)
+        if cb is not None and ctx.needs_input_grad[first + i]:
+            cb(p)
 
 
 def deliver_grads(params, grads):

@@ -10,7 +10,7 @@ import torch
 from torch import nn, Tensor
 
 from . import ops, weightprep
-from .runtime import compute_dtype_for, as_tokens_nhwc, drop_path_keep, deliver_grads
+from .runtime import compute_dtype_for, as_tokens_nhwc, drop_path_keep, deliver_grads, expect_grads
 from .shapes import MIT_VARIANTS, MIT_HEADS, MIT_SR, MIT_PATCH
 
 
@@ -143,6 +143,7 @@ class _ParamFn(torch.autograd.Function):
         P = dict(zip(names, params))
         out, S = cls.fwd(P, x.detach(), meta)
         ctx.S, ctx.meta, ctx.names, ctx.params = S, meta, names, params
+        expect_grads(ctx, params, 3)
         return out
 
     @classmethod

@@ -15,3 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """write what the parity tests measured (tests/_parity.py) to gpurun_out/parity_errors.json"""
+    try:
+        import _parity
+        _parity.dump()
+    except Exception:           # never let bookkeeping fail a run
+        pass

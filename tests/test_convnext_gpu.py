@@ -10,14 +10,8 @@ from semseg_amd import shapes
 pytestmark = pytest.mark.gpu
 
 
-def rel(a, b):
-    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
-    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
+from _parity import rel, rel_l2  # noqa: E402,F401  (recording error measures)
 
-
-def rel_l2(a, b):
-    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
-    return float((a - b).norm() / b.norm())
 
 
 def test_state_dict_layout_matches_reference_manifest():

@@ -50,6 +50,29 @@ def _worker(rank, world, port, out):
         loss.backward()
         scale = red.wait()
         res[f'grad{step}'] = (flat.grad * scale).clone()
+    # a module used twice before ONE backward: no bucket may travel before the second use's gradient has been added (CPU
+    # tensors reach the reducer through autograd, which sums the two uses before its single AccumulateGrad per parameter)
+    flat.zero_grad()
+    lo = rank * 4
+    loss = (((net(xs[lo:lo + 2]) - ys[lo:lo + 2]) ** 2).sum() + ((net(xs[lo + 2:lo + 4]) - ys[lo + 2:lo + 4]) ** 2).sum()) / 20
+    loss.backward()
+    res['grad_twice'] = (flat.grad * red.wait()).clone()
+    # a second backward after the buckets have travelled must raise, not silently desynchronise the ranks
+    flat.zero_grad()
+    ((net(xs[lo:lo + 4]) - ys[lo:lo + 4]) ** 2).mean().backward()
+    try:
+        ((net(xs[lo:lo + 4]) - ys[lo:lo + 4]) ** 2).mean().backward()
+        res['late_raises'] = False
+    except RuntimeError as e:
+        res['late_raises'] = 'after its bucket' in str(e)
+    red.wait()
+    # ... and accumulation over two backward passes works with overlap off
+    red.close()
+    red2 = GradReducer(flat, bucket_bytes=1024, overlap=False)
+    flat.zero_grad()
+    for half in (0, 2):
+        (((net(xs[lo + half:lo + half + 2]) - ys[lo + half:lo + half + 2]) ** 2).sum() / 20).backward()
+    res['grad_accum'] = (flat.grad * red2.wait()).clone()
     res['param_views_ok'] = all(p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
     # C2: every rank adds its own tiles' counts; the int64 all-reduce makes every rank see the union
     met = SegmentationMetrics(4, ignore_index=0)
@@ -79,6 +102,10 @@ def test_bucketed_grad_allreduce_and_confmat_sum_world2(tmp_path):
         for step in range(2):
             got = torch.cat([r[f'grad{step}'][o:o + n] for o, n in _layout(net)])
             assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
+        for key in ('grad_twice', 'grad_accum'):
+            got = torch.cat([r[key][o:o + n] for o, n in _layout(net)])
+            assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), key
+        assert r['late_raises']
     assert torch.equal(r0['grad0'], r1['grad0']) and torch.equal(r0['cm'], r1['cm']) and torch.equal(r0['miou'], r1['miou'])
     cms = []
     for rank in (0, 1):

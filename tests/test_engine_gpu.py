@@ -96,6 +96,14 @@ def _ddp_worker(rank, world, port, out):
         (net(x[lo:lo + 2]) * proj[lo:lo + 2]).sum().backward()
         red.wait()
         res[f'grad{step}'] = flat.grad.cpu().clone()
+    # the network called twice before ONE backward: every parameter receives two deliveries (runtime.deliver_grads); a bucket
+    # must not travel after the first one.  Eval mode: images are independent, so the sum equals the two-image batch above.
+    flat.zero_grad()
+    lo = rank * 2
+    ((net(x[lo:lo + 1]) * proj[lo:lo + 1]).sum() + (net(x[lo + 1:lo + 2]) * proj[lo + 1:lo + 2]).sum()).backward()
+    assert all(e == 2 for e in red.expected) and all(g == 2 for g in red.got)
+    red.wait()
+    res['grad_twice'] = flat.grad.cpu().clone()
     res['launched_all'] = True
     torch.save(res, os.path.join(out, f'r{rank}.pt'))
     dist.destroy_process_group()
@@ -122,4 +130,5 @@ def test_flat_gradient_allreduce_world2_on_one_gpu(tmp_path):
             g = r[f'grad{step}']
             assert g.shape == ref.shape
             assert float((g - ref).abs().max()) <= 2e-4 * float(ref.abs().max()), step
-    assert torch.equal(r0['grad1'], r1['grad1'])
+        assert float((r['grad_twice'] - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+    assert torch.equal(r0['grad1'], r1['grad1']) and torch.equal(r0['grad_twice'], r1['grad_twice'])

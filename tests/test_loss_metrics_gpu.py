@@ -9,9 +9,7 @@ from semseg_amd.detinit import det_input, det_labels
 pytestmark = pytest.mark.gpu
 
 
-def rel(a, b):
-    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
-    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
+from _parity import rel, rel_l2  # noqa: E402,F401  (recording error measures)
 
 
 def test_ohem_ce_matches_reference_golden(golden_dir):
@@ -92,6 +90,23 @@ def test_dice_losses_match_reference_golden(golden_dir):
         assert rel(p.grad, g[f'dicef.{smooth}.grad']) < 1e-4
     w = class_weights(torch.from_numpy(g['lab_many_ignored']).cuda(), torch.arange(8).cuda())
     assert rel(w, g['class_weights8']) < 1e-6
+    # any class ids in any order (the reference compares labels with the ids it is given, helper/weights.py:22)
+    from oracle import losses as olosses
+    ids = torch.tensor([5, 2, 7, 0, 3])
+    w2 = class_weights(torch.from_numpy(g['lab']).cuda(), ids.cuda())
+    assert rel(w2, olosses.class_weights(torch.from_numpy(g['lab']), ids)) < 1e-6
+    with pytest.raises(ValueError):
+        class_weights(lab, torch.tensor([0, 5000]).cuda())
+
+
+def test_label_hist_exact_full_size():
+    from semseg_amd import ops
+    torch.manual_seed(3)
+    lab = torch.randint(-2, 9, (16, 1024, 1024), device='cuda')            # values outside 0..5 are not counted
+    h = ops.label_hist(lab, 6)
+    want = torch.bincount(lab[(lab >= 0) & (lab < 6)].reshape(-1), minlength=6)
+    assert h.dtype == torch.int64 and torch.equal(h, want)
+    assert torch.equal(ops.label_hist(lab[:1, :3, :5].contiguous() * 0 + 4095, 4096)[4095:], torch.tensor([15], device='cuda'))
 
 
 def test_confusion_matrix_bit_exact_and_scores():

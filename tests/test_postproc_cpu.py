@@ -51,3 +51,26 @@ def test_statistics_against_sklearn():
         for i in range(6):
             row = cm[i] / ts[i] if ts[i] else np.eye(6)[i]
             np.testing.assert_allclose(st['norm_cm'][i], row, rtol=0, atol=0)
+
+
+def test_scores_from_confmat_exact_beyond_2_24():
+    """derived scores from counts that float32 cannot hold (one 16 x 1024^2 step already has 2^24 pixels): integer sums, one
+    rounding at the end (the counts used to be converted to float32 before the sums)."""
+    from fractions import Fraction
+    import torch
+    from semseg_amd.metrics import scores_from_confmat
+    cm = torch.tensor([[2 ** 33 + 1, 3, 0], [5, 2 ** 25 + 3, 0], [0, 0, 0]], dtype=torch.int64)
+    out = scores_from_confmat(cm)
+    c = cm.tolist()
+    tp = [c[i][i] for i in range(3)]
+    fp = [sum(c[r][i] for r in range(3)) - tp[i] for i in range(3)]
+    fn = [sum(c[i]) - tp[i] for i in range(3)]
+    f32 = lambda fr: float(torch.tensor(float(fr), dtype=torch.float64).float())
+    for i in range(2):
+        assert float(out['Precision'][i]) == f32(Fraction(tp[i], tp[i] + fp[i]))
+        assert float(out['Recall'][i]) == f32(Fraction(tp[i], tp[i] + fn[i]))
+        assert float(out['IoU'][i]) == f32(Fraction(tp[i], tp[i] + fp[i] + fn[i]))
+        assert float(out['F1'][i]) == f32(Fraction(2 * tp[i], 2 * tp[i] + fp[i] + fn[i]))
+    assert torch.isnan(out['Precision'][2]) and float(out['IoU'][2]) == 1.0          # absent class: NaN / absent_score 1.0
+    assert float(out['Global Accuracy']) == f32(Fraction(sum(tp), sum(map(sum, c))))
+    assert out['Confusion_Matrix'].dtype == torch.int64

@@ -8,14 +8,8 @@ import torch
 from semseg_amd.detinit import det_fill_, det_input
 
 
-def rel(a, b):
-    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
-    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
+from _parity import rel, rel_l2  # noqa: E402,F401  (recording error measures)
 
-
-def rel_l2(a, b):
-    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
-    return float((a - b).norm() / b.norm())
 
 
 VARIANTS = {'T_simple': ('T', 'sum', {'alias': 'simple'}), 'S_simple': ('S', 'sum', {'alias': 'simple'}), 'B_simple': ('B', 'sum', {'alias': 'simple'}),
