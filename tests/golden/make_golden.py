@@ -35,8 +35,24 @@ def np_(t):
     return t.detach().cpu().numpy()
 
 
+DEVS = {}                # oracle-vs-reference deviation per checked tensor: two fp32 CPU evaluation orders of the same maths, i.e.
+                         # the fp32 noise floor of that tensor; stored in the fixtures as 'dev.<name>' (GPU tests may widen the
+                         # 1e-4 gradient bar to 2x this value where a chain of training-mode BatchNorms amplifies rounding)
+
+
+def f64dev(save, name, v32, v64):
+    """'f64dev.<name>' = deviation of the reference's OWN fp32 result from its float64 evaluation of the same graph: how far fp32
+    rounding alone moves this tensor.  A GPU fp32 result cannot be asked to sit closer to the fp32 reference than that."""
+    save['f64dev.' + name] = np.float32(rel(v32.double(), v64))
+
+
+def devs(prefix):
+    return {'dev.' + k[len(prefix):]: np.float32(v) for k, v in DEVS.items() if k.startswith(prefix)}
+
+
 def check(name, a, b, tol=2e-5):
     r = rel(a, b)
+    DEVS[name] = r
     print(f'  oracle-vs-reference {name}: rel {r:.2e}')
     # analytically-zero quantities (e.g. a bias in front of a training-mode BN) are pure rounding noise
     assert r < tol or float((a - b).abs().max()) < 1e-6, (name, r)
@@ -88,6 +104,15 @@ def gen_mit():
         save[f'out{i}'] = np_(outs[i])
     for k in GRAD_KEYS_ENC:
         save['grad.' + k] = np_(grads[k])
+    enc64 = det_fill_(SegFormer('B0')).double().eval()
+    outs64 = enc64(x.double())
+    sum((o * p.double()).sum() for o, p in zip(outs64, projs)).backward()
+    g64 = {k: p.grad for k, p in enc64.named_parameters()}
+    for i in range(4):
+        f64dev(save, f'out{i}', outs[i], outs64[i])
+    for k in GRAD_KEYS_ENC:
+        f64dev(save, 'grad.' + k, grads[k], g64[k])
+    save.update(devs('mit.'))
     np.savez_compressed(os.path.join(HERE, 'mit_b0_64.npz'), **save)
 
 
@@ -119,6 +144,18 @@ def gen_head(training):
         save[f'dfeat{i}'] = np_(feats[i].grad)
     for k in GRAD_KEYS_HEAD:
         save['grad.' + k] = np_(grads[k])
+    head64 = det_fill_(LawinHead(chans, 128, 6)).double()
+    head64.train(training)
+    head64.dropout.p = 0.0
+    f64 = [f.detach().double().requires_grad_(True) for f in feats]
+    out64 = head64(f64)
+    (out64 * proj.double()).sum().backward()
+    g64 = {k: p.grad for k, p in head64.named_parameters()}
+    f64dev(save, 'out', out, out64)
+    for i in range(4):
+        f64dev(save, f'dfeat{i}', feats[i].grad, f64[i].grad)
+    for k in GRAD_KEYS_HEAD:
+        f64dev(save, 'grad.' + k, grads[k], g64[k])
     if training:
         # the reference's OWN bf16 path (torch.autocast) on the same inputs: its deviation from fp32 is the noise floor the
         # bf16 GPU tests measure our deviation against (a 2e-2 budget that the reference itself misses cannot be a bar)
@@ -140,6 +177,7 @@ def gen_head(training):
                   'cat.bn.num_batches_tracked'):
             check(f'head.train.{k}', sd[k].float(), after[k].float())
             save['after.' + k] = np_(after[k])
+    save.update(devs(f'head.{tag}.'))
     np.savez_compressed(os.path.join(HERE, f'lawin_e128_{tag}.npz'), **save)
 
 
@@ -160,6 +198,7 @@ def gen_head_e256():
     for i in range(4):
         check(f'head256.dfeat{i}', ofe[i].grad, feats[i].grad, 5e-5)
         save[f'dfeat{i}'] = np_(feats[i].grad)
+    save.update(devs('head256.'))
     np.savez_compressed(os.path.join(HERE, 'lawin_e256_eval.npz'), **save)
 
 
@@ -269,6 +308,15 @@ def gen_convnext():
     for k in keys:
         check(f'cnx.grad.{k}', sd[k].grad, grads[k], 5e-5)
         save['grad.' + k] = np_(grads[k])
+    enc64 = det_fill_(ConvNeXt('X')).double().eval()
+    outs64 = enc64(x.double())
+    sum((o * p.double()).sum() for o, p in zip(outs64, projs)).backward()
+    g64 = {k: p.grad for k, p in enc64.named_parameters()}
+    for i in range(4):
+        f64dev(save, f'out{i}', outs[i], outs64[i])
+    for k in keys:
+        f64dev(save, 'grad.' + k, grads[k], g64[k])
+    save.update(devs('cnx.'))
     np.savez_compressed(os.path.join(HERE, 'convnext_x_64.npz'), **save)
 
 
@@ -304,6 +352,28 @@ def gen_dnet():
     for k in ('decoder.deconvolution.net.1.running_mean', 'decoder.deconvolution.net.1.running_var', 'decoder.deconvolution.net.1.num_batches_tracked'):
         check(f'dnet.after.{k}', sd[k].float(), after[k].float())
         save['after.' + k] = np_(after[k])
+    net64 = det_fill_(DNet(3, 6, embed_dim=128, stem_code='X')).double().train()
+    net64.decoder.decoder.dropout.p = 0.0
+    p64 = net64(x.double())
+    DiceLoss(0.5, False, 6)(p64, lab).backward()
+    g64 = {k: p.grad for k, p in net64.named_parameters()}
+    f64dev(save, 'probs', probs, p64)
+    for k in keys:
+        f64dev(save, 'grad.' + k, grads[k], g64[k])
+    # the reference's OWN bf16 path (torch.autocast) on the same inputs, as gen_head does: the noise floor of a bf16 run
+    net_b = det_fill_(DNet(3, 6, embed_dim=128, stem_code='X')).train()
+    net_b.decoder.decoder.dropout.p = 0.0
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        pb = net_b(x)
+    lb = DiceLoss(0.5, False, 6)(pb.float(), lab)
+    lb.backward()
+    gb = {k: p.grad for k, p in net_b.named_parameters()}
+    save['bf16.probs'], save['bf16.loss'] = np_(pb.float()), np_(lb)
+    for k in keys:
+        save['bf16.grad.' + k] = np_(gb[k])
+    print('  bf16-autocast vs fp32: probs rel-L2', float((pb.float() - probs).norm() / probs.norm()),
+          ' worst grad rel-L2', max(float((gb[k] - grads[k]).norm() / grads[k].norm()) for k in keys))
+    save.update(devs('dnet.'))
     np.savez_compressed(os.path.join(HERE, 'dnet_x_128.npz'), **save)
 
 

@@ -56,3 +56,85 @@ def test_full_size_training_step_reaches_every_parameter():
     # biases that sit directly before a training-mode BatchNorm have an analytically zero gradient
     dead = [n for n in dead if not (n.endswith('.bias') and ('lawin' in n or 'conv' in n))]
     assert not dead, dead[:8]
+
+
+# ---------------------------------------------------------------------------- configs[2]: DNet(ConvNeXt-T + Decoder(embed 256)), 1024^2, bf16
+def _dead(net):
+    return [n for n, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all() or float(p.grad.abs().max()) == 0.0]
+
+
+def test_full_size_dnet_t_training_step_and_batch_independence():
+    """ConvNeXt-T (dims up to 768, depth 9: never built by the small-fixture tests) + Decoder + terminator at 2 x 1024^2 in bf16:
+    the probabilities of a training step sum to one at every pixel, the Dice step reaches every parameter, and eval-mode
+    probabilities of an image do not depend on its batch neighbours."""
+    from semseg_amd.decoder import DNet
+    from semseg_amd.loss import DiceLoss
+    from semseg_amd.runtime import set_compute_dtype
+    from semseg_amd.detinit import det_fill_, det_input, det_labels
+    net = det_fill_(DNet(3, 6, embed_dim=256, stem_code='T')).cuda().train()
+    x = det_input('full.dnet.x', (2, 3, 1024, 1024), 0, 1).cuda()
+    lab = det_labels('full.dnet.lab', (2, 1024, 1024), 6, cell=32).cuda()
+    set_compute_dtype(torch.bfloat16)
+    try:
+        probs = net(x)
+        assert probs.shape == (2, 6, 1024, 1024) and probs.dtype == torch.bfloat16
+        assert float((probs.float().sum(1) - 1).abs().max()) < 2e-2 and float(probs.min()) >= 0
+        loss = DiceLoss(0.5, False, 6)(probs, lab)
+        loss.backward()
+        assert torch.isfinite(loss) and 0 < float(loss) < 1
+        # a bias in front of a training-mode BatchNorm has an analytically zero gradient
+        dead = [n for n in _dead(net) if not (n.endswith('.bias') and ('lawin' in n or 'conv' in n))]
+        assert not dead, dead[:8]
+        net.eval()
+        with torch.no_grad():
+            both = net(x).float()
+            one = [net(x[i:i + 1]).float() for i in range(2)]
+    finally:
+        set_compute_dtype(None)
+    for i in range(2):
+        assert float((both[i] - one[i][0]).abs().max()) <= 2.0 ** -7, i          # probabilities: absolute, one bf16 rounding step of a split-K plan
+    assert float((both[0] - both[1]).abs().max()) > 1e-3
+
+
+# ---------------------------------------------------------------------------- configs[4]: MiT-B5 + Lawin(512), 2048^2, bf16, OHEM-CE + Dice
+def test_full_size_mit_b5_2048_ce_dice_step_and_confusion_matrix():
+    """MiT-B5 (depths 3/6/40/3) at 2 x 2048^2: N = 262144 queries, Nk = 4096 keys -- the regime of the attention backward that no
+    small fixture reaches.  One OHEM-CE + Dice training step reaches every parameter with finite gradients; the confusion matrix of
+    the step's logits adds up to the pixel count with the label histogram as its row sums; eval logits are batch-independent."""
+    from semseg_amd.model import SegFormerLawin
+    from semseg_amd.loss import OhemCEDiceLoss
+    from semseg_amd.metrics import SegmentationMetrics
+    from semseg_amd.runtime import set_compute_dtype
+    from semseg_amd.detinit import det_fill_, det_input, det_labels
+    net = SegFormerLawin('B5', 512, 6)
+    det_fill_(net.encoder), det_fill_(net.decoder)
+    net = net.cuda().train()
+    assert [len(getattr(net.encoder, f'block{i}')) for i in (1, 2, 3, 4)] == [3, 6, 40, 3]
+    x = det_input('full.b5.x', (2, 3, 2048, 2048), 0, 1).cuda()
+    lab = det_labels('full.b5.lab', (2, 2048, 2048), 6, cell=64).cuda()
+    set_compute_dtype(torch.bfloat16)
+    try:
+        out = net(x)
+        assert out.shape == (2, 6, 2048, 2048)
+        loss = OhemCEDiceLoss(6, 0, 0.7, 0.1)(out, lab)
+        loss.backward()
+        assert torch.isfinite(loss)
+        dead = [n for n in _dead(net) if not (n.endswith('.bias') and ('lawin' in n or 'conv' in n))]
+        assert not dead, dead[:8]
+        met = SegmentationMetrics(6, ignore_index=0).cuda()
+        met.update(out.detach(), lab)
+        cm = met.confmat
+        assert int(cm.sum()) == 2 * 2048 * 2048
+        assert torch.equal(cm.sum(1), torch.bincount(lab.reshape(-1), minlength=6))
+        assert torch.equal(cm.sum(0), torch.bincount(out.detach().float().argmax(1).reshape(-1), minlength=6))
+        del out, loss
+        net.eval()
+        with torch.no_grad():
+            both = net(x).float()
+            one0 = net(x[:1]).float()
+    finally:
+        set_compute_dtype(None)
+    scale = float(both.abs().max())
+    assert torch.isfinite(both).all()
+    assert float((both[0] - one0[0]).abs().max()) <= 2.0 ** -7 * scale
+    assert float((both[0] - both[1]).abs().max()) > 1e-3 * scale

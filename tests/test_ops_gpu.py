@@ -232,6 +232,26 @@ def test_mit_attention(ops, dtype, B, N, Nk, heads, D):
     assert rel(dkv, kvr.grad) < _tol(dtype) * 2
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,N,Nk,heads,D', [(1, 4096, 1024, 2, 64), (2, 1024, 1024, 1, 64), (1, 4096, 4096, 1, 64), (1, 2048, 4096, 5, 64),
+                                            (1, 1000, 4100, 1, 32)])
+def test_mit_attention_headline_key_counts(ops, dtype, B, N, Nk, heads, D):
+    """Nk = 1024 is what every stage of the headline (configs[1], 1024^2) runs, Nk = 4096 what configs[4] (MiT-B5, 2048^2) runs:
+    the key loop of the forward and both backward kernels over many key tiles (and a ragged one), against plain fp32 torch."""
+    C = heads * D
+    qq, kv, do = rnd(B * N, C), rnd(B * Nk, 2 * C, seed=1), rnd(B * N, C, seed=2)
+    qr, kvr = q(qq, dtype).requires_grad_(True), q(kv, dtype).requires_grad_(True)
+    qh = qr.view(B, N, heads, D).transpose(1, 2)
+    k, v = kvr.view(B, Nk, 2, heads, D).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(qh @ k.transpose(-2, -1) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, C)
+    ref.backward(q(do, dtype))
+    o, lse = ops.mit_attn_fwd(dev(qq, dtype), dev(kv, dtype), B, N, Nk, heads)
+    assert rel(o, ref) < _tol(dtype)
+    dq, dkv = ops.mit_attn_bwd(dev(qq, dtype), dev(kv, dtype), o, dev(do, dtype), lse, B, N, Nk, heads)
+    assert rel(dq, qr.grad) < _tol(dtype) * 2
+    assert rel(dkv, kvr.grad) < _tol(dtype) * 2
+
+
 def test_mit_attention_online_softmax_rescale(ops):
     """a key far larger than the rest, placed in a late key tile, forces the running-max rescale branch"""
     B, N, Nk, heads, D = 1, 64, 200, 1, 64
