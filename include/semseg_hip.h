@@ -267,11 +267,13 @@ int ss_decoder_combine_bwd(int dtype, const void* dprod, const void* z9, int64_t
                            float* dbias_grad, int B, int H4, int W4, int oc, float* workspace, int64_t ws_bytes, hipStream_t stream);
 /* ---- core/dnet.py:45-51 + MultilabelClassifier (modules/layers.py:25-43): nearest resize (Hd,Wd) -> (H,W) (torch's float index
  * rule), 1x1 conv oc -> nc + bias, Softmax2d.  probs / dprobs: NCHW [B,nc,H,W]; wt [nc][oc], bt [nc] fp32.
- * ss_terminator_bwd: dprod [B,Hd,Wd,oc], dw_db = [nc*oc + nc] fp32; workspace >= 1024*(nc*oc + nc) floats. */
-int ss_terminator_fwd(int dtype, const void* prod, const float* wt, const float* bt, void* probs, int B, int Hd, int Wd, int H, int W,
-                      int oc, int nc, hipStream_t stream);
-int ss_terminator_bwd(int dtype, const void* dprobs, const void* prod, const float* wt, const float* bt, void* dprod, float* dw_db,
-                      int B, int Hd, int Wd, int H, int W, int oc, int nc, float* workspace, int64_t ws_bytes, hipStream_t stream);
+ * ss_terminator_bwd: dprod [B,Hd,Wd,oc], dw_db = [nc*oc + nc] fp32; workspace >= 1024*(nc*oc + nc) floats.
+ * probs_f32 != 0: probs / dprobs are fp32 whatever `dtype` is (torch.autocast runs softmax in fp32, so the reference's reduced-
+ * precision path hands fp32 probabilities to DiceLoss; 6 channels at full resolution: +0.2 GB of traffic per 16 x 1024^2 step). */
+int ss_terminator_fwd(int dtype, int probs_f32, const void* prod, const float* wt, const float* bt, void* probs, int B, int Hd, int Wd, int H,
+                      int W, int oc, int nc, hipStream_t stream);
+int ss_terminator_bwd(int dtype, int probs_f32, const void* dprobs, const void* prod, const float* wt, const float* bt, void* dprod,
+                      float* dw_db, int B, int Hd, int Wd, int H, int W, int oc, int nc, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
 /* ---- TopFormer token pyramid (modules/topformer.py, modules/heads.py, core/models.py), inference.
  * ss_im2col_ex: im2col with the asymmetric AutoPadding of modules/layers.py:146-164 (3x3 / s2 stem, :213-250).
@@ -317,8 +319,9 @@ int ss_image_affine(int out_dtype, const float* in, int64_t ldi, const float* M,
 /* ---- optimizer step right after the gradient all-reduce: AdaBound as configured in train.py:53-58
  * (torch_optimizer.AdaBound, absent here: restated from Luo et al. 2019, parity unpinned) over FLAT fp32 buffers -- one launch
  * for the whole model.  step_size / lower / upper are the per-step scalars of the published algorithm (host computed);
- * grad_scale multiplies g first (1/world_size when the all-reduce summed). */
-int ss_adabound_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+ * grad_scale multiplies g first (1/world_size when the all-reduce summed).  The betas are doubles: 1 - beta is taken in double and
+ * rounded to float once, as torch does with the python scalars of exp_avg.mul_(beta).add_(grad, alpha=1 - beta). */
+int ss_adabound_step(float* p, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, float eps,
                      float step_size, float lower, float upper, float weight_decay, float grad_scale, hipStream_t stream);
 
 /* ---- gradient delivery: dst[i][0..numel[i]) += src[i] for `count` fp32 tensors in one launch per 40 tensors.  Source i is

@@ -269,9 +269,9 @@ __global__ __launch_bounds__(256) void decoder_combine_bwd_fixed_kernel(const T*
 struct TermGeom { int B, Hd, Wd, H, W, oc, nc; float sy, sx; };
 __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) { int s = (int)floorf(dst * scale); return s < in_size - 1 ? s : in_size - 1; }
 
-template <typename T>
+template <typename T, typename TP>
 __global__ __launch_bounds__(256) void terminator_fwd_kernel(const T* __restrict__ prod, const float* __restrict__ wt, const float* __restrict__ bt,
-        T* __restrict__ probs, TermGeom g) {
+        TP* __restrict__ probs, TermGeom g) {
     const int64_t total = (int64_t)g.B * g.H * g.W, hw = (int64_t)g.H * g.W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int X = (int)(i % g.W); int64_t q = i / g.W; const int Y = (int)(q % g.H); const int64_t b = q / g.H;
@@ -291,15 +291,15 @@ __global__ __launch_bounds__(256) void terminator_fwd_kernel(const T* __restrict
         for (int c = 0; c < DEC_MAXC; ++c) if (c < g.nc) { lg[c] = __expf(lg[c] - mx); den += lg[c]; }
         const float inv = 1.f / den;
 #pragma unroll
-        for (int c = 0; c < DEC_MAXC; ++c) if (c < g.nc) probs[(b * g.nc + c) * hw + (int64_t)Y * g.W + X] = from_f<T>(lg[c] * inv);
+        for (int c = 0; c < DEC_MAXC; ++c) if (c < g.nc) probs[(b * g.nc + c) * hw + (int64_t)Y * g.W + X] = from_f<TP>(lg[c] * inv);
     }
 }
 
 // DNet's own channel counts known at compile time (nc = 6 classes, oc = 6 or 12): the generic kernel above walks DEC_MAXC
 // predicated slots per pixel; here the product row is read as 4-byte pairs and everything unrolls to nc * oc fmas.
-template <typename T, int NC, int OC>
+template <typename T, typename TP, int NC, int OC>
 __global__ __launch_bounds__(256) void terminator_fwd_fixed_kernel(const T* __restrict__ prod, const float* __restrict__ wt, const float* __restrict__ bt,
-        T* __restrict__ probs, TermGeom g) {
+        TP* __restrict__ probs, TermGeom g) {
     __shared__ float ws[NC * OC + NC];
     for (int t = threadIdx.x; t < NC * OC + NC; t += blockDim.x) ws[t] = t < NC * OC ? wt[t] : bt[t - NC * OC];
     __syncthreads();
@@ -324,14 +324,14 @@ __global__ __launch_bounds__(256) void terminator_fwd_fixed_kernel(const T* __re
         for (int c = 0; c < NC; ++c) { lg[c] = __expf(lg[c] - mx); den += lg[c]; }
         const float inv = 1.f / den;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) probs[(b * NC + c) * hw + (int64_t)Y * g.W + X] = from_f<T>(lg[c] * inv);
+        for (int c = 0; c < NC; ++c) probs[(b * NC + c) * hw + (int64_t)Y * g.W + X] = from_f<TP>(lg[c] * inv);
     }
 }
 
 // one thread per SOURCE pixel of the (Hd,Wd) map: softmax backward is linear in dprobs, so the destination pixels that share the
 // source are summed first.  dprod written; dW (nc*oc) and db (nc) as per-workgroup partials [blk][nc*oc + nc].
-template <typename T>
-__global__ __launch_bounds__(256) void terminator_bwd_kernel(const T* __restrict__ dprobs, const T* __restrict__ prod, const float* __restrict__ wt,
+template <typename T, typename TP>
+__global__ __launch_bounds__(256) void terminator_bwd_kernel(const TP* __restrict__ dprobs, const T* __restrict__ prod, const float* __restrict__ wt,
         const float* __restrict__ bt, T* __restrict__ dprod, float* __restrict__ partial, TermGeom g) {
     extern __shared__ float shp[];                                   // [4][nc*oc + nc]
     const int ncols = g.nc * g.oc + g.nc;
@@ -395,8 +395,8 @@ __global__ __launch_bounds__(256) void terminator_bwd_kernel(const T* __restrict
 // The same with the channel counts known at compile time (DNet: nc = oc): every thread keeps its share of dW / db in NC*OC + NC
 // registers over the whole grid-stride loop and the wave reductions run once per workgroup instead of NC*OC + NC times per pixel
 // (9.5 ms per DNet step at 1024^2 went into those shuffles).
-template <typename T, int NC, int OC>
-__global__ __launch_bounds__(256) void terminator_bwd_fixed_kernel(const T* __restrict__ dprobs, const T* __restrict__ prod, const float* __restrict__ wt,
+template <typename T, typename TP, int NC, int OC>
+__global__ __launch_bounds__(256) void terminator_bwd_fixed_kernel(const TP* __restrict__ dprobs, const T* __restrict__ prod, const float* __restrict__ wt,
         const float* __restrict__ bt, T* __restrict__ dprod, float* __restrict__ partial, TermGeom g) {
     constexpr int NCOLS = NC * OC + NC;
     __shared__ float shp[4][NCOLS];
@@ -546,38 +546,46 @@ static int term_geom(TermGeom* g, int B, int Hd, int Wd, int H, int W, int oc, i
     return 0;
 }
 
-extern "C" int ss_terminator_fwd(int dtype, const void* prod, const float* wt, const float* bt, void* probs, int B, int Hd, int Wd, int H, int W,
-                                 int oc, int nc, hipStream_t stream) {
+// probs_f32 != 0: the probabilities (and their gradient) are fp32 whatever the compute dtype -- what torch.autocast does with softmax
+#define SS_TERM_DISPATCH(dtype, probs_f32, ...) \
+    do { if ((dtype) == SS_F32) { typedef float T; typedef float TP; __VA_ARGS__; } \
+         else if ((dtype) == SS_BF16 && (probs_f32)) { typedef bf16 T; typedef float TP; __VA_ARGS__; } \
+         else if ((dtype) == SS_BF16) { typedef bf16 T; typedef bf16 TP; __VA_ARGS__; } \
+         else return ss_fail(-1, "unsupported dtype code %d", (int)(dtype)); } while (0)
+
+extern "C" int ss_terminator_fwd(int dtype, int probs_f32, const void* prod, const float* wt, const float* bt, void* probs, int B, int Hd, int Wd,
+                                 int H, int W, int oc, int nc, hipStream_t stream) {
     SS_CHECK(prod && wt && bt && probs, "ss_terminator_fwd: null pointer");
     TermGeom g; if (term_geom(&g, B, Hd, Wd, H, W, oc, nc, "ss_terminator_fwd")) return -1;
     dim3 grid(dec_blocks((int64_t)B * H * W, 32768));
     if (nc == 6 && oc == 12)
-        SS_DISPATCH(dtype, hipLaunchKernelGGL((terminator_fwd_fixed_kernel<T, 6, 12>), grid, dim3(256), 0, stream, (const T*)prod, wt, bt, (T*)probs, g));
+        SS_TERM_DISPATCH(dtype, probs_f32, hipLaunchKernelGGL((terminator_fwd_fixed_kernel<T, TP, 6, 12>), grid, dim3(256), 0, stream, (const T*)prod, wt, bt, (TP*)probs, g));
     else if (nc == 6 && oc == 6)
-        SS_DISPATCH(dtype, hipLaunchKernelGGL((terminator_fwd_fixed_kernel<T, 6, 6>), grid, dim3(256), 0, stream, (const T*)prod, wt, bt, (T*)probs, g));
+        SS_TERM_DISPATCH(dtype, probs_f32, hipLaunchKernelGGL((terminator_fwd_fixed_kernel<T, TP, 6, 6>), grid, dim3(256), 0, stream, (const T*)prod, wt, bt, (TP*)probs, g));
     else
-        SS_DISPATCH(dtype, hipLaunchKernelGGL((terminator_fwd_kernel<T>), grid, dim3(256), 0, stream, (const T*)prod, wt, bt, (T*)probs, g));
+        SS_TERM_DISPATCH(dtype, probs_f32, hipLaunchKernelGGL((terminator_fwd_kernel<T, TP>), grid, dim3(256), 0, stream, (const T*)prod, wt, bt, (TP*)probs, g));
     SS_LAUNCH_CHECK();
     return 0;
 }
 
 // dw_db: [nc*oc + nc] fp32 (weight gradient row-major [nc][oc], then the bias gradient); workspace >= 1024 * (nc*oc + nc) floats
-extern "C" int ss_terminator_bwd(int dtype, const void* dprobs, const void* prod, const float* wt, const float* bt, void* dprod, float* dw_db,
-                                 int B, int Hd, int Wd, int H, int W, int oc, int nc, float* workspace, int64_t ws_bytes, hipStream_t stream) {
+extern "C" int ss_terminator_bwd(int dtype, int probs_f32, const void* dprobs, const void* prod, const float* wt, const float* bt, void* dprod,
+                                 float* dw_db, int B, int Hd, int Wd, int H, int W, int oc, int nc, float* workspace, int64_t ws_bytes,
+                                 hipStream_t stream) {
     SS_CHECK(dprobs && prod && wt && bt && dprod && dw_db && workspace, "ss_terminator_bwd: null pointer");
     TermGeom g; if (term_geom(&g, B, Hd, Wd, H, W, oc, nc, "ss_terminator_bwd")) return -1;
     const int ncols = nc * oc + nc;
     const int nb = dec_blocks((int64_t)B * Hd * Wd, 1024);
     SS_CHECK(ws_bytes >= (int64_t)nb * ncols * 4, "ss_terminator_bwd: workspace too small");
     if (nc == 6 && oc == 12) {                            // DNet(n_classes = 6): the decoder hands 2 * n_classes channels to the classifier
-        SS_DISPATCH(dtype, hipLaunchKernelGGL((terminator_bwd_fixed_kernel<T, 6, 12>), dim3(nb), dim3(256), 0, stream, (const T*)dprobs, (const T*)prod, wt, bt,
-                                              (T*)dprod, workspace, g));
+        SS_TERM_DISPATCH(dtype, probs_f32, hipLaunchKernelGGL((terminator_bwd_fixed_kernel<T, TP, 6, 12>), dim3(nb), dim3(256), 0, stream, (const TP*)dprobs,
+                                                               (const T*)prod, wt, bt, (T*)dprod, workspace, g));
     } else if (nc == 6 && oc == 6) {
-        SS_DISPATCH(dtype, hipLaunchKernelGGL((terminator_bwd_fixed_kernel<T, 6, 6>), dim3(nb), dim3(256), 0, stream, (const T*)dprobs, (const T*)prod, wt, bt,
-                                              (T*)dprod, workspace, g));
+        SS_TERM_DISPATCH(dtype, probs_f32, hipLaunchKernelGGL((terminator_bwd_fixed_kernel<T, TP, 6, 6>), dim3(nb), dim3(256), 0, stream, (const TP*)dprobs,
+                                                               (const T*)prod, wt, bt, (T*)dprod, workspace, g));
     } else {
-        SS_DISPATCH(dtype, hipLaunchKernelGGL((terminator_bwd_kernel<T>), dim3(nb), dim3(256), 4 * ncols * sizeof(float), stream, (const T*)dprobs,
-                                              (const T*)prod, wt, bt, (T*)dprod, workspace, g));
+        SS_TERM_DISPATCH(dtype, probs_f32, hipLaunchKernelGGL((terminator_bwd_kernel<T, TP>), dim3(nb), dim3(256), 4 * ncols * sizeof(float), stream,
+                                                               (const TP*)dprobs, (const T*)prod, wt, bt, (T*)dprod, workspace, g));
     }
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(ncols, 8), 1), dim3(256), 0, stream, workspace, nb, ncols, 1.f, dw_db, 0);

@@ -8,7 +8,7 @@
 //   step = clamp(step_size / (sqrt(v) + eps), lower, upper) * m;  p -= step
 // with step_size = lr * sqrt(1-b2^t) / (1-b1^t), lower = flr (1 - 1/(gamma t + 1)), upper = flr (1 + 1/(gamma t)) computed on the host.
 __global__ __launch_bounds__(256) void adabound_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-        float* __restrict__ v, int64_t n4, int64_t n, float b1, float b2, float eps, float step_size, float lower, float upper,
+        float* __restrict__ v, int64_t n4, int64_t n, float b1, float b2, float omb1, float omb2, float eps, float step_size, float lower, float upper,
         float wd, float gscale) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -16,8 +16,8 @@ __global__ __launch_bounds__(256) void adabound_kernel(float* __restrict__ p, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float gr = gv[e] * gscale + wd * pv[e];
-            mv[e] = b1 * mv[e] + (1.f - b1) * gr;
-            vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+            mv[e] = b1 * mv[e] + omb1 * gr;
+            vv[e] = b2 * vv[e] + omb2 * gr * gr;
             float s = step_size / (sqrtf(vv[e]) + eps);
             s = fminf(fmaxf(s, lower), upper);
             pv[e] -= s * mv[e];
@@ -27,20 +27,21 @@ __global__ __launch_bounds__(256) void adabound_kernel(float* __restrict__ p, co
     // tail (n not a multiple of 4)
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float gr = g[i] * gscale + wd * p[i];
-        float mm = b1 * m[i] + (1.f - b1) * gr, vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        float mm = b1 * m[i] + omb1 * gr, vv = b2 * v[i] + omb2 * gr * gr;
         float s = fminf(fmaxf(step_size / (sqrtf(vv) + eps), lower), upper);
         p[i] -= s * mm; m[i] = mm; v[i] = vv;
     }
 }
 
-extern "C" int ss_adabound_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+extern "C" int ss_adabound_step(float* p, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, float eps,
                                 float step_size, float lower, float upper, float weight_decay, float grad_scale, hipStream_t stream) {
     SS_CHECK(n >= 0, "ss_adabound_step: n < 0");
     if (n == 0) return 0;
     SS_CHECK(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "ss_adabound_step: buffers must be 16-byte aligned");
     int64_t n4 = n / 4;
     int blocks = (int)(cdiv(n4 > 0 ? n4 : 1, 256) < 4096 ? cdiv(n4 > 0 ? n4 : 1, 256) : 4096);
-    hipLaunchKernelGGL(adabound_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n4, n, beta1, beta2, eps, step_size, lower,
+    hipLaunchKernelGGL(adabound_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n4, n, (float)beta1, (float)beta2,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2) /* rounded once from the double, as torch rounds alpha = 1 - beta */, eps, step_size, lower,
                        upper, weight_decay, grad_scale);
     SS_LAUNCH_CHECK();
     return 0;

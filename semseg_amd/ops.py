@@ -861,15 +861,15 @@ def decoder_combine_bwd(dprod, z9, bs, dbias, stats, gamma, beta, training, B, H
     return dz9, dbs, dgb, dbg
 
 
-def terminator_fwd(prod, wt, bt, B, Hd, Wd, H, W):
-    """prod [B*Hd*Wd, oc] -> probabilities NCHW [B, nc, H, W]."""
+def terminator_fwd(prod, wt, bt, B, Hd, Wd, H, W, probs_f32=False):
+    """prod [B*Hd*Wd, oc] -> probabilities NCHW [B, nc, H, W] (fp32 when probs_f32, else prod's dtype)."""
     dev = _dev(prod)
     nc, oc = wt.shape
     _f32(wt, 'wt'), _f32(bt, 'bt', nc)
     if not prod.is_contiguous() or prod.shape != (B * Hd * Wd, oc):
         raise ValueError('terminator_fwd: bad prod')
-    probs = torch.empty((B, nc, H, W), dtype=prod.dtype, device=dev)
-    check(lib().ss_terminator_fwd(dt(prod), _p(prod), _p(wt), _p(bt), _p(probs), B, Hd, Wd, H, W, oc, nc, _stream()))
+    probs = torch.empty((B, nc, H, W), dtype=torch.float32 if probs_f32 else prod.dtype, device=dev)
+    check(lib().ss_terminator_fwd(dt(prod), int(probs_f32), _p(prod), _p(wt), _p(bt), _p(probs), B, Hd, Wd, H, W, oc, nc, _stream()))
     return probs
 
 
@@ -877,12 +877,13 @@ def terminator_bwd(dprobs, prod, wt, bt, B, Hd, Wd, H, W):
     """-> dprod [B*Hd*Wd, oc], dW [nc, oc] fp32, db [nc] fp32."""
     dev = _dev(prod)
     nc, oc = wt.shape
-    if not dprobs.is_contiguous() or dprobs.dtype != prod.dtype or dprobs.shape != (B, nc, H, W):
+    if not dprobs.is_contiguous() or dprobs.dtype not in (prod.dtype, torch.float32) or dprobs.shape != (B, nc, H, W):
         raise ValueError('terminator_bwd: dprobs must be contiguous NCHW like the probabilities')
+    probs_f32 = dprobs.dtype == torch.float32
     dprod = torch.empty_like(prod)
     out = torch.empty(nc * oc + nc, dtype=torch.float32, device=dev)
     ws = workspace(dev, COLRED_BLOCKS * (nc * oc + nc) * 4)
-    check(lib().ss_terminator_bwd(dt(prod), _p(dprobs), _p(prod), _p(wt), _p(bt), _p(dprod), _p(out), B, Hd, Wd, H, W, oc, nc, _p(ws), ws.numel(),
+    check(lib().ss_terminator_bwd(dt(prod), int(probs_f32), _p(dprobs), _p(prod), _p(wt), _p(bt), _p(dprod), _p(out), B, Hd, Wd, H, W, oc, nc, _p(ws), ws.numel(),
                                   _stream()))
     return dprod, out[:nc * oc].view(nc, oc), out[nc * oc:]
 

@@ -112,6 +112,14 @@ def gen_mit():
         f64dev(save, f'out{i}', outs[i], outs64[i])
     for k in GRAD_KEYS_ENC:
         f64dev(save, 'grad.' + k, grads[k], g64[k])
+    # the reference's OWN bf16 path (torch.autocast), as gen_head: the noise floor a bf16 engine is measured against
+    enc_b = det_fill_(SegFormer('B0')).eval()
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        outs_b = enc_b(x)
+    sum((o.float() * p).sum() for o, p in zip(outs_b, projs)).backward()
+    gb = {k: p.grad for k, p in enc_b.named_parameters()}
+    for k in GRAD_KEYS_ENC:
+        save['bf16.grad.' + k] = np_(gb[k])
     save.update(devs('mit.'))
     np.savez_compressed(os.path.join(HERE, 'mit_b0_64.npz'), **save)
 
@@ -316,6 +324,13 @@ def gen_convnext():
         f64dev(save, f'out{i}', outs[i], outs64[i])
     for k in keys:
         f64dev(save, 'grad.' + k, grads[k], g64[k])
+    enc_b = det_fill_(ConvNeXt('X')).eval()
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        outs_b = enc_b(x)
+    sum((o.float() * p).sum() for o, p in zip(outs_b, projs)).backward()
+    gb = {k: p.grad for k, p in enc_b.named_parameters()}
+    for k in keys:
+        save['bf16.grad.' + k] = np_(gb[k])
     save.update(devs('cnx.'))
     np.savez_compressed(os.path.join(HERE, 'convnext_x_64.npz'), **save)
 

@@ -33,7 +33,7 @@ def test_convnext_x_fp32_matches_reference_golden(golden_dir):
     params = dict(enc.named_parameters())
     for k in g.files:
         if k.startswith('grad.'):
-            assert rel(params[k[5:]].grad, g[k]) < 3e-4, k
+            assert rel(params[k[5:]].grad, g[k]) < 1e-4, k
 
 
 def test_convnext_x_bf16_within_budget(golden_dir):
@@ -52,7 +52,7 @@ def test_convnext_x_bf16_within_budget(golden_dir):
         assert outs[i].dtype == torch.bfloat16 and rel_l2(outs[i], g[f'out{i}']) < 2e-2, i
     params = dict(enc.named_parameters())
     for k in ('grad.stages.1.0.pw_conv1.weight', 'grad.stages.3.1.dw_conv.weight', 'grad.downsample_layers.2.1.weight'):
-        assert rel_l2(params[k[5:]].grad, g[k]) < 4e-2, k
+        assert rel_l2(params[k[5:]].grad, g[k]) < max(2e-2, 1.5 * rel_l2(g['bf16.' + k], g[k])), k     # see test_mit_gpu.py
 
 
 def test_dnet_training_step_fp32_matches_reference_golden(golden_dir):
@@ -72,7 +72,7 @@ def test_dnet_training_step_fp32_matches_reference_golden(golden_dir):
     params = dict(net.named_parameters())
     for k in g.files:
         if k.startswith('grad.'):
-            assert rel(params[k[5:]].grad, g[k]) < 1e-3, k
+            assert rel(params[k[5:]].grad, g[k]) < 1e-4, k
     sd = net.state_dict()
     for k in g.files:
         if k.startswith('after.'):
@@ -81,7 +81,7 @@ def test_dnet_training_step_fp32_matches_reference_golden(golden_dir):
 
 def test_dnet_training_step_bf16_within_reference_bf16_budget(golden_dir):
     """The bf16 instantiations of the decoder / terminator kernels (what configs[2] runs on): probabilities within 2e-2 of the fp32
-    reference; every listed gradient within max(2e-2, 1.25 x the deviation of the reference's OWN bf16-autocast run from its fp32
+    reference; every listed gradient within max(2e-2, 1.5 x the deviation of the reference's OWN bf16-autocast run from its fp32
     run) -- the fixture's bf16.* vectors: the chain of training-mode BatchNorms makes that deviation 2e-2 .. 2.5e-1 here."""
     from semseg_amd.decoder import DNet
     from semseg_amd.loss import DiceLoss
@@ -98,16 +98,16 @@ def test_dnet_training_step_bf16_within_reference_bf16_budget(golden_dir):
         loss.backward()
     finally:
         set_compute_dtype(None)
-    assert probs.dtype == torch.bfloat16 and probs.shape == (2, 6, 128, 128)
+    assert probs.dtype == torch.float32 and probs.shape == (2, 6, 128, 128)      # softmax output is fp32, as under torch.autocast
     assert rel_l2(probs, g['probs']) < 2e-2
-    assert float((probs.float().sum(1) - 1).abs().max()) < 2e-2
+    assert float((probs.sum(1) - 1).abs().max()) < 1e-5
     assert rel(loss, g['loss']) < 2e-2
     params = dict(net.named_parameters())
     for k in g.files:
         if k.startswith('grad.'):
             ref_dev = float(np.linalg.norm(g['bf16.' + k] - g[k]) / np.linalg.norm(g[k]))
             assert params[k[5:]].grad.dtype == torch.float32
-            assert rel_l2(params[k[5:]].grad, g[k]) < max(2e-2, 1.25 * ref_dev), (k, ref_dev)
+            assert rel_l2(params[k[5:]].grad, g[k]) < max(2e-2, 1.5 * ref_dev), (k, ref_dev)
 
 
 def test_decoder_eval_nonsquare_vs_oracle():
@@ -129,6 +129,6 @@ def test_decoder_eval_nonsquare_vs_oracle():
     (oout * proj).sum().backward()
     assert rel(out, oout) < 1e-4
     for i in range(4):
-        assert rel(feats[i].grad, fr[i].grad) < 5e-4, i
+        assert rel(feats[i].grad, fr[i].grad) < 1e-4, i
     for k in ('deconvolution.net.0.weight', 'deconvolution.net.0.bias', 'deconvolution.net.1.weight', 'feature_reducer.net.p_conv.conv.weight'):
-        assert rel(dict(dec.named_parameters())[k].grad, sd[k].grad) < 5e-4, k
+        assert rel(dict(dec.named_parameters())[k].grad, sd[k].grad) < 1e-4, k

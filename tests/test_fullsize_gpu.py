@@ -77,8 +77,8 @@ def test_full_size_dnet_t_training_step_and_batch_independence():
     set_compute_dtype(torch.bfloat16)
     try:
         probs = net(x)
-        assert probs.shape == (2, 6, 1024, 1024) and probs.dtype == torch.bfloat16
-        assert float((probs.float().sum(1) - 1).abs().max()) < 2e-2 and float(probs.min()) >= 0
+        assert probs.shape == (2, 6, 1024, 1024) and probs.dtype == torch.float32          # softmax output is fp32, as under autocast
+        assert float((probs.sum(1) - 1).abs().max()) < 1e-5 and float(probs.min()) >= 0
         loss = DiceLoss(0.5, False, 6)(probs, lab)
         loss.backward()
         assert torch.isfinite(loss) and 0 < float(loss) < 1

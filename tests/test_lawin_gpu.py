@@ -59,11 +59,11 @@ def test_lawin_head_fp32_matches_reference_golden(golden_dir, training):
     head, feats, out = _head_run(training, torch.float32)
     assert rel(out, g['out']) < 1e-4
     for i in range(4):
-        assert rel(feats[i].grad, g[f'dfeat{i}']) < 3e-4, i
+        assert rel(feats[i].grad, g[f'dfeat{i}']) < 1e-4, i
     params = dict(head.named_parameters())
     for k in g.files:
         if k.startswith('grad.'):
-            assert grad_close(params, k[5:], g[k], lambda n: g['grad.' + n] if 'grad.' + n in g.files else None, 3e-4), k
+            assert grad_close(params, k[5:], g[k], lambda n: g['grad.' + n] if 'grad.' + n in g.files else None, 1e-4), k
     if training:
         sd = head.state_dict()
         for k in g.files:
@@ -88,7 +88,7 @@ def test_lawin_head_e256_matches_reference_golden(golden_dir, dtype):
     if dtype == torch.float32:
         assert rel(out, g['out']) < 1e-4
         for i in range(4):
-            assert rel(feats[i].grad, g[f'dfeat{i}']) < 3e-4, i
+            assert rel(feats[i].grad, g[f'dfeat{i}']) < 1e-4, i
     else:
         assert rel_l2(out, g['out']) < 2e-2
         for i in range(4):
@@ -133,10 +133,10 @@ def test_lawin_head_dropout_mask_and_nonsquare_vs_oracle(monkeypatch):
     (oout * proj).sum().backward()
     assert rel(out, oout) < 1e-4
     for i in range(4):
-        assert rel(feats[i].grad, fr[i].grad) < 3e-4
+        assert rel(feats[i].grad, fr[i].grad) < 1e-4
     params = dict(head.named_parameters())
     for k in params:
-        assert grad_close(params, k, sd[k].grad, lambda n: sd[n].grad, 5e-4), k
+        assert grad_close(params, k, sd[k].grad, lambda n: sd[n].grad, 1e-4), k
 
 
 def test_segmentor_logits_loss_grads_match_reference_golden(golden_dir):
@@ -155,10 +155,10 @@ def test_segmentor_logits_loss_grads_match_reference_golden(golden_dir):
     loss = crit(out, lab)
     loss.backward()
     assert rel(loss, g['loss']) < 1e-4
-    assert rel(net.encoder.block1[0].attn.q.weight.grad, g['grad.enc.block1.0.attn.q.weight']) < 5e-4
-    assert rel(net.encoder.patch_embed1.proj.weight.grad, g['grad.enc.patch_embed1.proj.weight']) < 5e-4
-    assert rel(net.decoder.linear_pred.weight.grad, g['grad.head.linear_pred.weight']) < 5e-4
-    assert rel(net.decoder.lawin_8.theta.weight.grad, g['grad.head.lawin_8.theta.weight']) < 5e-4
+    assert rel(net.encoder.block1[0].attn.q.weight.grad, g['grad.enc.block1.0.attn.q.weight']) < 1e-4
+    assert rel(net.encoder.patch_embed1.proj.weight.grad, g['grad.enc.patch_embed1.proj.weight']) < 1e-4
+    assert rel(net.decoder.linear_pred.weight.grad, g['grad.head.linear_pred.weight']) < 1e-4
+    assert rel(net.decoder.lawin_8.theta.weight.grad, g['grad.head.lawin_8.theta.weight']) < 1e-4
     # bf16: within the 2e-2 budget of the fp32 reference logits (the reference's own bf16 autocast sits at 1.7e-2)
     from semseg_amd.runtime import set_compute_dtype
     set_compute_dtype(torch.bfloat16)

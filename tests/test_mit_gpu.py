@@ -1,5 +1,6 @@
 """MiT encoder on the GPU (HIP path through the C ABI) vs the golden vectors captured from the reference and vs the
-CPU oracle on the same seeded inputs.  fp32: 1e-4 relative; bf16: 2e-2 (relative L2), as BASELINE.json's north star."""
+CPU oracle on the same seeded inputs.  fp32: 1e-4 relative on outputs AND gradients; bf16: 2e-2 (relative L2) on outputs, gradients within max(2e-2, 1.5 x the reference's
+own bf16-autocast deviation).  Measured values: gpurun_out/parity_errors.json, DESIGN.md section 5."""
 import os
 import numpy as np
 import pytest
@@ -38,7 +39,7 @@ def test_mit_b0_fp32_matches_reference_golden(golden_dir):
     grads = dict(enc.named_parameters())
     for k in g.files:
         if k.startswith('grad.'):
-            assert rel(grads[k[5:]].grad, g[k]) < 2e-4, k
+            assert rel(grads[k[5:]].grad, g[k]) < 1e-4, k
 
 
 def test_mit_b0_bf16_matches_reference_golden(golden_dir):
@@ -51,7 +52,9 @@ def test_mit_b0_bf16_matches_reference_golden(golden_dir):
     for k in g.files:
         if k.startswith('grad.'):
             assert grads[k[5:]].grad.dtype == torch.float32
-            assert rel_l2(grads[k[5:]].grad, g[k]) < 4e-2, k
+            # 2e-2, or 1.5 x the deviation of the reference's OWN bf16-autocast gradient from its fp32 one where that is larger
+            # (bf16.* vectors of the fixture: 0.5e-2 .. 1.6e-2 here; the reference keeps its residual stream in fp32 under autocast)
+            assert rel_l2(grads[k[5:]].grad, g[k]) < max(2e-2, 1.5 * rel_l2(g['bf16.' + k], g[k])), k
 
 
 def test_mit_b0_training_droppath_vs_oracle(monkeypatch):
@@ -85,7 +88,7 @@ def test_mit_b0_training_droppath_vs_oracle(monkeypatch):
     for i in range(4):
         assert rel(outs[i], oouts[i]) < 1e-4
     for k, p in enc.named_parameters():
-        assert rel(p.grad, sd[k].grad) < 3e-4, k
+        assert rel(p.grad, sd[k].grad) < 1e-4, k
 
 
 def test_submodule_api_matches_oracle():
@@ -105,7 +108,7 @@ def test_submodule_api_matches_oracle():
         xr = x.clone().requires_grad_(True)
         yr = fn(sd, xr)
         yr.sum().backward()
-        assert rel(y, yr) < 1e-4 and rel(xd.grad, xr.grad) < 2e-4, type(mod).__name__
+        assert rel(y, yr) < 1e-4 and rel(xd.grad, xr.grad) < 1e-4, type(mod).__name__
     pe = det_fill_(sf.PatchEmbed(64, 128, 3, 2)).cuda()
     img = det_input('sub.img', (2, 64, 10, 14), -1, 1)
     xd = img.cuda().requires_grad_(True)
@@ -115,4 +118,4 @@ def test_submodule_api_matches_oracle():
     xr = img.clone().requires_grad_(True)
     yr, hr, wr = omit.patch_embed(sd, 'p', xr, 3, 2)
     yr.sum().backward()
-    assert (ho, wo) == (hr, wr) and rel(y, yr) < 1e-4 and rel(xd.grad, xr.grad) < 2e-4
+    assert (ho, wo) == (hr, wr) and rel(y, yr) < 1e-4 and rel(xd.grad, xr.grad) < 1e-4

@@ -1,5 +1,5 @@
 """GPU unit tests of the HIP kernels (through the C ABI) against plain fp32 PyTorch-CPU maths of the same op.
-Tolerances: fp32 1e-4 relative (north star), bf16 2e-2 relative to the tensor's max magnitude."""
+Tolerances: _tol / _gtol below; what each site measured is in gpurun_out/parity_errors.json."""
 import math
 import pytest
 import torch
@@ -10,6 +10,13 @@ DTYPES = [torch.float32, torch.bfloat16]
 
 
 def _tol(dtype):
+    """outputs: fp32 1e-4 (north star); bf16 1e-2 of the tensor's max magnitude (measured <= 4e-3; the north star's 2e-2 is a relative
+    L2 bound on whole-network outputs)"""
+    return 1e-4 if dtype == torch.float32 else 1e-2
+
+
+def _gtol(dtype):
+    """gradients of a single op: fp32 1e-4, bf16 2e-2 (measured <= 8e-3)"""
     return 1e-4 if dtype == torch.float32 else 2e-2
 
 
@@ -171,8 +178,8 @@ def test_batchnorm(ops, dtype, rows, C, act):
     y = ops.bn_apply(dev(z, dtype), stats, dev(g), dev(b), act, res=dev(res, dtype), mask=dev(mask), rows_per_image=rows // B)
     assert rel(y, ref) < _tol(dtype)
     dz, dgb = ops.bn_bwd(dev(dy, dtype), dev(z, dtype), stats, dev(g), dev(b), act, mask=dev(mask), rows_per_image=rows // B)
-    assert rel(dz, zr.grad) < _tol(dtype) * 2
-    assert rel(dgb[0], gr.grad) < 2e-4 and rel(dgb[1], br.grad) < 2e-4
+    assert rel(dz, zr.grad) < _gtol(dtype)
+    assert rel(dgb[0], gr.grad) < 1e-4 and rel(dgb[1], br.grad) < 1e-4
     # eval mode
     zr2 = q(z, dtype).requires_grad_(True)
     ref2 = F.batch_norm(zr2.t()[None], rm, rv, g, b, False, 0.1, 1e-5)[0].t()
@@ -208,9 +215,9 @@ def test_dwconv3(ops, dtype, B, H, W, C):
     assert rel(y.view(B, H, W, C), ref.permute(0, 2, 3, 1)) < _tol(dtype)
     g, dwdb = ops.dwconv3_bwd(dyd, xd, w9c, dev(b), B, H, W, act=1)
     dx = ops.dwconv3_fwd(g, w9c_flip, None, B, H, W, act=0)
-    assert rel(dx.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _tol(dtype) * 2
-    assert rel(dwdb[:9].t().reshape(C, 1, 3, 3), wr.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
-    assert rel(dwdb[9], br.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+    assert rel(dx.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _gtol(dtype)
+    assert rel(dwdb[:9].t().reshape(C, 1, 3, 3), wr.grad) < _gtol(dtype)
+    assert rel(dwdb[9], br.grad) < _gtol(dtype)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -228,8 +235,8 @@ def test_mit_attention(ops, dtype, B, N, Nk, heads, D):
     dq, dkv = ops.mit_attn_bwd(dev(qq, dtype), dev(kv, dtype), o, dev(do, dtype), lse, B, N, Nk, heads)
     # Nk == 1 makes dq analytically zero: compare against the gradient scale of the op instead of max|ref| = 0
     scale_q = max(float(qr.grad.abs().max()), 0.05)
-    assert float((dq.float().cpu() - qr.grad).abs().max()) / scale_q < _tol(dtype) * 2
-    assert rel(dkv, kvr.grad) < _tol(dtype) * 2
+    assert float((dq.float().cpu() - qr.grad).abs().max()) / scale_q < _gtol(dtype)
+    assert rel(dkv, kvr.grad) < _gtol(dtype)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -248,8 +255,8 @@ def test_mit_attention_headline_key_counts(ops, dtype, B, N, Nk, heads, D):
     o, lse = ops.mit_attn_fwd(dev(qq, dtype), dev(kv, dtype), B, N, Nk, heads)
     assert rel(o, ref) < _tol(dtype)
     dq, dkv = ops.mit_attn_bwd(dev(qq, dtype), dev(kv, dtype), o, dev(do, dtype), lse, B, N, Nk, heads)
-    assert rel(dq, qr.grad) < _tol(dtype) * 2
-    assert rel(dkv, kvr.grad) < _tol(dtype) * 2
+    assert rel(dq, qr.grad) < _gtol(dtype)
+    assert rel(dkv, kvr.grad) < _gtol(dtype)
 
 
 def test_mit_attention_online_softmax_rescale(ops):
@@ -283,7 +290,7 @@ def test_im2col_conv(ops, dtype, C, k, s, pad):
     if C % 8 == 0:
         dcol = ops.gemm_nt(dyd, wpt)
         dx = ops.col2im(dcol, B, H, W, C, k, s, pad)
-        assert rel(dx.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _tol(dtype) * 2
+        assert rel(dx.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _gtol(dtype)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -340,8 +347,8 @@ def test_lawin_window_attention(ops, dtype, B, H, W, inter, heads):
     y, lse = ops.lawin_attn_fwd(dev(theta, dtype), dev(pg, dtype), B, H, W, heads)
     assert rel(y, ref) < _tol(dtype)
     dth, dpg = ops.lawin_attn_bwd(dev(theta, dtype), dev(pg, dtype), y, dev(dy, dtype), lse, B, H, W, heads)
-    assert rel(dth, tr.grad) < _tol(dtype) * 2
-    assert rel(dpg, pr.grad) < _tol(dtype) * 2
+    assert rel(dth, tr.grad) < _gtol(dtype)
+    assert rel(dpg, pr.grad) < _gtol(dtype)
     # theta / y as channel slices of wider buffers (how LawinHead calls it)
     wide = dev(rnd(B * H * W, inter + 16, seed=4), dtype)
     y2, _ = ops.lawin_attn_fwd(wide[:, 8:8 + inter], dev(pg, dtype), B, H, W, heads)
