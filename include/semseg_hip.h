@@ -208,6 +208,15 @@ int ss_dice_sums(int dtype, const void* probs, int64_t sn, int64_t sc, int64_t s
                  int C, int H, int W, float* sums, float* workspace, int64_t ws_bytes, hipStream_t stream);
 int ss_dice_bwd(int dtype, const int64_t* labels, const float* coef_hit, const float* coef_all, const float* gout, void* dprobs,
                 int64_t on, int64_t oc, int64_t oh, int64_t ow, int B, int C, int H, int W, hipStream_t stream);
+/* ss_dice_sums_static: ss_dice_sums for callers that CANNOT ALLOCATE -- code under HIP graph capture, tight serving / evaluation
+ * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same kernels, same results bit for bit; the
+ * per-workgroup partial sums live in a 1 MiB file-scope device array (one copy per GPU, held until the process ends) instead of a
+ * caller workspace, and the call performs no allocation of any kind.  Limit: B * min(64, ceil(H*W / 4096)) * 3 * C <=
+ * ss_dice_sums_static_max_floats() (= 262144; e.g. B = 16, C = 85 at 1024 x 1024), beyond which it fails with a message.  Calls
+ * that overlap on one GPU (different streams) race on the array: serialise them. */
+int64_t ss_dice_sums_static_max_floats(void);
+int ss_dice_sums_static(int dtype, const void* probs, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels, int B,
+                        int C, int H, int W, float* sums, hipStream_t stream);
 /* helper/weights.py:18-22 (class_weights: the label frequencies; the reference compares every pixel with every class id in a
  * [pixels x classes] boolean matrix): hist[v] += #(labels == v) for v in [0, nbins), int64, exact; other values are not counted. */
 int ss_label_hist(const int64_t* labels, int64_t n, int nbins, int64_t* hist, hipStream_t stream);

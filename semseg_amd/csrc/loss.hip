@@ -7,6 +7,7 @@
 // stable-order tie rule AND its quirk (the index found among the VALID pixels is applied to the ALL-pixel vector,
 // loss/seg_loss.py:141-143), the stateful never-decreasing threshold (:143-144), then a fixed-order masked mean.
 #include "common.h"
+#include <mutex>
 
 struct Strides { int64_t n, c, h, w; };
 struct OhemCtl {
@@ -584,6 +585,52 @@ extern "C" int ss_dice_sums(int dtype, const void* probs, int64_t sn, int64_t sc
                                           (const long long*)labels, workspace, H, W, C));
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(dice_sums_final_kernel, dim3((unsigned)cdiv(3 * C, 256), B), dim3(256), 0, stream, workspace, nb, 3 * C, sums);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+// ---- the same sums for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc): the
+// per-workgroup partial sums go to a file-scope device array instead of a caller workspace.  Each GPU the library runs on holds
+// its own copy of the array at its own address until the process ends; the address is looked up once per device
+// (hipGetSymbolAddress with that device current) and only that pointer is ever handed to kernels.  Every partial the finalize
+// kernel reads is written by the launch before it, so nothing needs clearing between calls; calls that overlap on one GPU
+// (two streams) race on the array.
+#define SS_DICE_SCRATCH_FLOATS (256 * 1024)          // 1 MiB per GPU
+static __device__ __align__(256) float scratch[SS_DICE_SCRATCH_FLOATS];
+#define SS_MAX_DEVICES 64
+static float* g_scratch_ptr[SS_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+static int dice_scratch_for_current_device(float** out) {
+    int dev = -1;
+    SS_HIP(hipGetDevice(&dev));
+    SS_CHECK(dev >= 0 && dev < SS_MAX_DEVICES, "ss_dice_sums_static: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* p = nullptr;
+        SS_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+        SS_CHECK(p != nullptr, "ss_dice_sums_static: hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+extern "C" int64_t ss_dice_sums_static_max_floats(void) { return SS_DICE_SCRATCH_FLOATS; }
+
+extern "C" int ss_dice_sums_static(int dtype, const void* probs, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,
+                                   int B, int C, int H, int W, float* sums, hipStream_t stream) {
+    SS_CHECK(probs && labels && sums && B > 0 && C > 0 && C <= 1024 && H > 0 && W > 0, "ss_dice_sums_static: bad arguments");
+    const int nb = (int)(cdiv((int64_t)H * W, 4096) < 64 ? cdiv((int64_t)H * W, 4096) : 64);
+    const int64_t need = (int64_t)B * nb * 3 * C;
+    SS_CHECK(need <= SS_DICE_SCRATCH_FLOATS, "ss_dice_sums_static: B * blocks * 3 * C = %lld partial sums exceed the static scratch of %d "
+             "floats (B %d, C %d, %d blocks per image); use ss_dice_sums with a workspace", (long long)need, SS_DICE_SCRATCH_FLOATS, B, C, nb);
+    float* part = nullptr;
+    if (int rc = dice_scratch_for_current_device(&part)) return rc;
+    Strides s{sn, sc, sh, sw};
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((dice_sums_kernel<T>), dim3(nb, B), dim3(256), 3 * C * sizeof(float), stream, (const T*)probs, s,
+                                          (const long long*)labels, part, H, W, C));
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dice_sums_final_kernel, dim3((unsigned)cdiv(3 * C, 256), B), dim3(256), 0, stream, part, nb, 3 * C, sums);
     SS_LAUNCH_CHECK();
     return 0;
 }
