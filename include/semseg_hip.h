@@ -100,6 +100,11 @@ int ss_dwconv3_fwd(int dtype, const void* x, const float* w9c, const float* bias
 int ss_dwconv3_bwd(int dtype, const void* dy, const void* x, const float* w9c, const float* bias, void* g, float* dw_db,
                    int B, int H, int W, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
+/* The backward in ONE pass (3 tensor passes instead of 5): dx = the gradient of the dwconv input, dw_db as above; g never reaches
+ * memory (column neighbours exchange it through LDS, rounded to the storage dtype as the stored g is).  dx must not alias dy / x. */
+int ss_dwconv3_bwd_fused(int dtype, const void* dy, const void* x, const float* w9c, const float* bias, void* dx, float* dw_db,
+                         int B, int H, int W, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
+
 /* ---- general depthwise k x k convolution on channels-last maps: ConvNeXt 7x7 s1 p3 (modules/convnext.py:27,39) and the TopFormer
  * token-pyramid 3x3 / 5x5, stride 1 / 2 with the asymmetric AutoPadding of modules/layers.py:146-164 (modules/topformer.py:166-184).
  * wkkc: tap-major [k*k][C] fp32.  act: 0 none, 1 GELU(erf), 2 ReLU, 3 ReLU6.  The data gradient (stride 1) is this entry point with

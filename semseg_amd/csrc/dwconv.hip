@@ -301,6 +301,198 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_kernel(const T* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------ fused backward (data gradient + weight gradient in one pass)
+// The two-pass backward above writes g = dy * act'(u) and a second forward-style pass reads it back for dx = dw_flipped(g):
+// 5 tensor passes where 3 suffice (dy and x in, dx out).  Here a workgroup owns XL image columns (the outer two are halo) of
+// one channel group and walks down a strip; a thread still keeps the 3x3 window of x in registers for ITS column, computes
+// g for its column and row r, hands it to its two column neighbours through LDS (one barrier per row, two row buffers), and
+// keeps the last three rows of g for the three columns in registers: dx[r-2] = sum_ky,kx w[ky][kx] g[r-1-ky][x+1-kx] follows
+// two rows behind (the neighbours' g is read from LDS one step before it is used).  g is rounded to the storage dtype before it is used, as the stored g of the two-pass form is, and never
+// reaches memory.  Halo rows (y0-1 and yend) and halo columns are computed twice (by both neighbours) and counted once.
+#ifndef DWF_UNR
+#define DWF_UNR 3
+#endif
+#ifndef DWF_NE
+#define DWF_NE 4
+#endif
+struct DwFGeom { int cpb, xl, groups, xtiles, ystrips, chunks, ty; };
+static inline DwFGeom dwf_geom(int B, int H, int W, int C, int ne) {
+    DwFGeom g; g.chunks = C / ne;
+    // XL columns per workgroup, XL - 2 of them produce output: wide enough to keep the halo share small, narrow enough that the
+    // chunk lanes of one image column still cover whole 128-byte lines where C allows it
+    int xl = 32;
+    while (xl > 8 && (256 / xl) * 2 <= g.chunks && (256 / xl) * ne * 2 < 64) xl >>= 1;     // at least 64 channels per pixel row if C has them
+    while (xl > 4 && 256 / xl < 1) xl >>= 1;
+    int cpb = 256 / xl;
+    while (cpb > 1 && cpb / 2 >= g.chunks) { cpb >>= 1; xl <<= 1; }                          // few channels: spend the lanes on columns
+    g.cpb = cpb; g.xl = xl; g.groups = (int)cdiv(g.chunks, cpb);
+    g.xtiles = (int)cdiv(W, xl - 2);
+    int best = 2 * DW_UNROLL; int64_t best_cost = -1;
+    for (int ty = 2 * DW_UNROLL; ty <= 8 * DW_UNROLL; ty += DW_UNROLL) {
+        const int64_t strips = cdiv(H, ty), cost = strips * (ty + 8);
+        const int64_t blocks = strips * g.xtiles * g.groups * B;
+        if (ty > 2 * DW_UNROLL && blocks < 1024) break;
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = ty; }
+    }
+    g.ty = best; g.ystrips = (int)cdiv(H, g.ty);
+    return g;
+}
+
+template <typename T, int NE, int ACT, int OCC, int UNR>
+__global__ __launch_bounds__(256, OCC) void dwconv3_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ w,
+        const float* __restrict__ bias, T* __restrict__ dxo, float* __restrict__ partial, int B, int H, int W, int C, DwFGeom g) {
+    typedef vecn<T, NE> V;
+    __shared__ float shf[256 * NE > 2 * 256 * NE * (int)sizeof(T) / 4 ? 256 * NE : 2 * 256 * NE * (int)sizeof(T) / 4];
+    V* gx = (V*)shf;                                        // [2][256] rows of g in flight between column neighbours
+    const int tid = threadIdx.x, cl = tid % g.cpb, xs = tid / g.cpb;
+    const int chunk_raw = blockIdx.y * g.cpb + cl;
+    const bool cok = chunk_raw < g.chunks;
+    const int chunk = cok ? chunk_raw : g.chunks - 1, c = chunk * NE;
+    const int tl = xs > 0 ? tid - g.cpb : tid, tr = xs + 1 < g.xl ? tid + g.cpb : tid;      // LDS slots of the column neighbours
+    float wt[9][NE], bv[NE], acc[10][NE];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) acc[k][e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) loadf<NE>(w + k * C + c, wt[k]);
+    loadf<NE>(bias + c, bv);
+    const int tiles_per_img = g.xtiles * g.ystrips, ntiles = B * tiles_per_img;
+    const int64_t rs = (int64_t)W * C;
+    int par = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / tiles_per_img, rem = tile % tiles_per_img;
+        const int xx = (rem % g.xtiles) * (g.xl - 2) - 1 + xs, y0 = (rem / g.xtiles) * g.ty;
+        const bool colok = xx >= 0 && xx < W;
+        const bool inner = colok && cok && xs > 0 && xs + 1 < g.xl;          // this lane's dx / dW are its own
+        const int xc = xx < 0 ? 0 : (xx < W ? xx : W - 1);
+        const bool lok = colok && xx > 0, rok = colok && xx + 1 < W;
+        const unsigned mC = colok ? ~0u : 0u, mL = lok ? ~0u : 0u, mR = rok ? ~0u : 0u;
+        const int offL = lok ? -C : 0, offR = rok ? C : 0;
+        const int yend = min(H, y0 + g.ty);
+        const int ylast = min(H - 1, yend + 1);                  // last row of x any g of the strip reads
+        const int dlast = min(H - 1, yend);                      // last row of dy
+        const int rb = max(y0 - 1, 0);                           // row the base pointers stand on
+        const int64_t off = (((int64_t)img * H + rb) * W + xc) * C + c;
+        const T* px = x + off;
+        const T* pd = dy + off;
+        T* po = dxo + off;
+        // g rows r = y0-1 .. yend, one per step; x rows r-1, r, r+1 in the window, r+2 .. r+4 travelling, dy rows r .. r+2 travelling
+        const int r0 = y0 - 1;
+        float win[3][3][NE], gw[3][3][NE];
+        V ring[3][3], dring[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) gw[a][b][e] = 0.f;
+        {
+            V raw[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {                         // rows r0-1, r0, r0+1
+                const int rr = r0 - 1 + j;
+                const unsigned k = (rr >= 0 && rr < H) ? ~0u : 0u;
+                dw_issue_row<T, NE>(px + (int64_t)(min(max(rr, 0), ylast) - rb) * rs, offL, offR, raw);
+                dw_cvt_row<T, NE>(raw, mL & k, mC & k, mR & k, win[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                dw_issue_row<T, NE>(px + (int64_t)(min(max(r0 + 2 + j, 0), ylast) - rb) * rs, offL, offR, ring[(2 + j) % 3]);
+                dring[j] = raw_load<T, NE>(pd + (int64_t)(min(max(r0 + j, 0), dlast) - rb) * rs);
+            }
+        }
+        const int nsteps = yend - y0 + 3;                        // rows y0-1 .. yend of g, and one more step: dx trails g by two rows
+        V gl, gr;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { gl[e] = (T)0.f; gr[e] = (T)0.f; }
+        for (int s0 = 0; s0 < nsteps; s0 += UNR) {
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) {
+                const int r = r0 + s0 + i;                        // the row of g this step produces
+                float u[NE], go[NE];
+                dw_taps<NE>(win[i % 3], win[(i + 1) % 3], win[(i + 2) % 3], wt, bv, u);
+                union { V v; unsigned w[sizeof(V) / 4]; } d;
+                d.v = dring[i % 3];
+                const unsigned live = (r >= 0 && r <= dlast && r <= yend && colok) ? ~0u : 0u;     // g is zero outside the image
+#pragma unroll
+                for (int j = 0; j < (int)(sizeof(V) / 4); ++j) d.w[j] &= live;
+                dring[i % 3] = raw_load<T, NE>(pd + (int64_t)(min(max(r + 3, 0), dlast) - rb) * rs);
+                V gv;
+                float dact[NE];
+                if (ACT == 1) {
+                    float cdf[NE], ez[NE];
+                    gelu_parts_v<NE>(u, cdf, ez);
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) dact[e] = fmaf(u[e] * 0.3989422804014327f, ez[e], cdf[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    go[e] = ACT == 1 ? (float)d.v[e] * dact[e] : (float)d.v[e];
+                    gv[e] = (T)go[e];
+                    go[e] = (float)gv[e];                         // the rounded g, as a stored g would be read back
+                }
+                gx[par * 256 + tid] = gv;
+                // While the row travels: dx of row r-2 from g rows r-1 (ky = 0), r-2 (ky = 1), r-3 (ky = 2), column x+1-kx.  The
+                // neighbours' g of row r-1 was read from LDS at the end of the previous step (gl / gr), a whole step of arithmetic
+                // ago, so nothing here waits for the LDS round trip.
+                {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) { gw[(i + 2) % 3][0][e] = (float)gl[e]; gw[(i + 2) % 3][2][e] = (float)gr[e]; }
+                    float o[NE];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) o[e] = 0.f;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) {
+                            o[e] = fmaf(wt[kx][e], gw[(i + 2) % 3][2 - kx][e], o[e]);
+                            o[e] = fmaf(wt[3 + kx][e], gw[(i + 1) % 3][2 - kx][e], o[e]);
+                            o[e] = fmaf(wt[6 + kx][e], gw[i % 3][2 - kx][e], o[e]);
+                        }
+                    V ov;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) ov[e] = (T)o[e];
+                    if (inner && r - 2 >= y0 && r - 2 < yend) *(V*)(po + (int64_t)(r - 2 - rb) * rs) = ov;
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) gw[i % 3][1][e] = go[e];          // slot of row r-3 is free now: row r moves in
+                // weight / bias gradient: own rows and own columns only (halo g belongs to the neighbouring workgroup)
+                const float own = (inner && r >= y0 && r < yend) ? 1.f : 0.f;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) { const float gm = go[e] * own; acc[9][e] += gm;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        acc[kx][e] = fmaf(gm, win[i % 3][kx][e], acc[kx][e]);
+                        acc[3 + kx][e] = fmaf(gm, win[(i + 1) % 3][kx][e], acc[3 + kx][e]);
+                        acc[6 + kx][e] = fmaf(gm, win[(i + 2) % 3][kx][e], acc[6 + kx][e]);
+                    } }
+                __syncthreads();
+                gl = gx[par * 256 + tl]; gr = gx[par * 256 + tr];                // consumed by the next step
+                par ^= 1;
+                const unsigned k = r + 2 < H ? ~0u : 0u;          // r + 2 >= y0 + 1 > 0
+                dw_cvt_row<T, NE>(ring[(i + 2) % 3], mL & k, mC & k, mR & k, win[i % 3]);
+                dw_issue_row<T, NE>(px + (int64_t)(min(max(r + 5, 0), ylast) - rb) * rs, offL, offR, ring[(i + 2) % 3]);
+            }
+        }
+    }
+    // combine the x lanes of each chunk lane through LDS in a fixed order
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NE; ++e) shf[tid * NE + e] = acc[k][e];
+        __syncthreads();
+        if (xs == 0 && cok) {
+            float* dst = partial + ((int64_t)blockIdx.x * 10 + k) * C + c;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { float sum = 0.f;
+                for (int j = 0; j < g.xl; ++j) sum += shf[(j * g.cpb + cl) * NE + e];
+                dst[e] = sum; }
+        }
+    }
+}
+
 extern "C" int ss_dwconv3_fwd(int dtype, const void* x, const float* w9c, const float* bias, void* y, int B, int H, int W, int C,
                               int act, hipStream_t stream) {
     SS_CHECK(x && w9c && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "ss_dwconv3_fwd: bad arguments (C=%d)", C);
@@ -335,6 +527,31 @@ extern "C" int ss_dwconv3_bwd(int dtype, const void* dy, const void* x, const fl
     else if (dtype == SS_F32) { if (act) SS_DW_BWD(float, 4, 1); else SS_DW_BWD(float, 4, 0); }
     else return ss_fail(-1, "ss_dwconv3_bwd: unsupported dtype %d", dtype);
 #undef SS_DW_BWD
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(10 * C, 8), 1), dim3(256), 0, stream, workspace, (int)nbg, 10 * C, 1.f, dw_db, 0);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx and dw_db in one pass: dx = d/dx of sum(dy * act(dw(x) + b)), dw_db = [10][C] fp32.  workspace: 1024 * 10 * C floats.
+extern "C" int ss_dwconv3_bwd_fused(int dtype, const void* dy, const void* x, const float* w9c, const float* bias, void* dx, float* dw_db,
+                                    int B, int H, int W, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(dy && x && w9c && bias && dx && dw_db && workspace && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "ss_dwconv3_bwd_fused: bad arguments");
+    SS_CHECK(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(w9c) && aligned16(bias), "ss_dwconv3_bwd_fused: pointers must be 16-byte aligned");
+    SS_CHECK(dx != dy && dx != x, "ss_dwconv3_bwd_fused: dx must not alias an input (neighbouring workgroups re-read the halo)");
+    DwFGeom geo = dwf_geom(B, H, W, C, 4);
+    const int64_t ntiles = (int64_t)B * geo.xtiles * geo.ystrips;
+    SS_CHECK(ntiles < 2147483647LL && geo.groups < 65536, "ss_dwconv3_bwd_fused: grid too large");
+    int64_t nbg = 1024 / geo.groups; if (nbg < 1) nbg = 1; if (nbg > ntiles) nbg = ntiles;
+    SS_CHECK(ws_bytes >= nbg * 10 * C * 4, "ss_dwconv3_bwd_fused: workspace too small");
+    dim3 grid((unsigned)nbg, geo.groups);
+    SS_CHECK(act == 0 || act == 1, "ss_dwconv3_bwd_fused: act must be 0 (none) or 1 (GELU)");
+    // fp32 (the parity path) keeps twice the bytes per window entry: one workgroup per SIMD pair there, two for bf16
+#define SS_DW_BWDF(T, NE, ACT) hipLaunchKernelGGL((dwconv3_bwd_fused_kernel<T, NE, ACT, sizeof(T) == 2 ? 2 : 1, DWF_UNR>), grid, dim3(256), 0, stream, (const T*)dy, (const T*)x, w9c, bias, (T*)dx, workspace, B, H, W, C, geo)
+    if (dtype == SS_BF16) { if (act) SS_DW_BWDF(bf16, DWF_NE, 1); else SS_DW_BWDF(bf16, DWF_NE, 0); }
+    else if (dtype == SS_F32) { if (act) SS_DW_BWDF(float, 4, 1); else SS_DW_BWDF(float, 4, 0); }
+    else return ss_fail(-1, "ss_dwconv3_bwd_fused: unsupported dtype %d", dtype);
+#undef SS_DW_BWDF
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(10 * C, 8), 1), dim3(256), 0, stream, workspace, (int)nbg, 10 * C, 1.f, dw_db, 0);
     SS_LAUNCH_CHECK();

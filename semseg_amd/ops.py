@@ -256,6 +256,20 @@ def dwconv3_bwd(dy, x, w9c, bias, B, H, W, act=0):
     return g, dwdb
 
 
+def dwconv3_bwd_fused(dy, x, w9c, bias, B, H, W, act=0):
+    """-> dx [rows, C] (gradient of the depthwise conv's input), dw_db [10, C] fp32 (9 taps tap-major, then bias): one pass."""
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    if ld != C or rows != B * H * W or dy.shape != x.shape or not dy.is_contiguous() or dy.dtype != x.dtype:
+        raise ValueError('dwconv3_bwd_fused: bad x / dy')
+    _f32(w9c, 'w9c', 9 * C), _f32(bias, 'bias', C)
+    dx = torch.empty_like(x)
+    dwdb = torch.empty((10, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, COLRED_BLOCKS * 10 * C * 4)
+    check(lib().ss_dwconv3_bwd_fused(dt(x), _p(dy), _p(x), _p(w9c), _p(bias), _p(dx), _p(dwdb), B, H, W, C, act, _p(ws), ws.numel(), _stream()))
+    return dx, dwdb
+
+
 # ------------------------------------------------------------------ MiT attention
 def mit_attn_fwd(q, kv, B, N, Nk, heads, scale=None):
     """q [B*N, C], kv [B*Nk, 2C] -> o [B*N, C], lse [B, heads, round32(N)]."""

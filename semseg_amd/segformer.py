@@ -89,6 +89,9 @@ def attn_backward(P, S, dout, B, h, w, head, sr):
 
 
 # ------------------------------------------------------------------ Mix-FFN (modules/segformer.py:44-64)
+FUSED_DW_MIN_PIXELS = 4096        # maps at least this large take the one-pass depthwise backward (measured crossover: 32 x 32 loses, 64 x 64 wins)
+
+
 def mlp_forward(P, x, B, h, w, res=None, keep=None):
     T = x.dtype
     h1 = ops.gemm_nt(x, w_fwd(P['fc1.weight'], T), bias=P['fc1.bias'])
@@ -106,11 +109,15 @@ def mlp_backward(P, S, dout, B, h, w):
     G['fc2.weight'], G['fc2.bias'] = linear_grads(dout, S['a2'])
     da2 = ops.gemm_nt(dout, w_bwd(P['fc2.weight'], T))
     Ch = da2.shape[1]
-    g, dwdb = ops.dwconv3_bwd(da2, S['h1'], S['w9c'], P['dw_conv.dw_conv.bias'], B, h, w, act=1)
+    if h * w >= FUSED_DW_MIN_PIXELS:
+        # one pass: dh1 and the tap / bias gradients together, g = da2 * GELU'(u) stays on chip (3 tensor passes instead of 5)
+        dh1, dwdb = ops.dwconv3_bwd_fused(da2, S['h1'], S['w9c'], P['dw_conv.dw_conv.bias'], B, h, w, act=1)
+    else:
+        # small maps (stage 4 of a 1024^2 tile is 32 x 32): too few column tiles per image for the halo exchange to pay
+        g, dwdb = ops.dwconv3_bwd(da2, S['h1'], S['w9c'], P['dw_conv.dw_conv.bias'], B, h, w, act=1)
+        dh1 = ops.dwconv3_fwd(g, w_taps(P['dw_conv.dw_conv.weight'], reverse=True), None, B, h, w, act=0)
     G['dw_conv.dw_conv.weight'] = ops.transpose_cast(dwdb[:9], torch.float32).reshape(Ch, 1, 3, 3)
     G['dw_conv.dw_conv.bias'] = dwdb[9]
-    w9c_flip = w_taps(P['dw_conv.dw_conv.weight'], reverse=True)
-    dh1 = ops.dwconv3_fwd(g, w9c_flip, None, B, h, w, act=0)
     G['fc1.weight'], G['fc1.bias'] = linear_grads(dh1, S['x'])
     dx = ops.gemm_nt(dh1, w_bwd(P['fc1.weight'], T))
     return dx, G

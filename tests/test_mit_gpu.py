@@ -30,7 +30,10 @@ def _run(dtype, x, projs_dtype=None):
     return enc, outs
 
 
-def test_mit_b0_fp32_matches_reference_golden(golden_dir):
+@pytest.mark.parametrize('fused_dw', [False, True])
+def test_mit_b0_fp32_matches_reference_golden(golden_dir, monkeypatch, fused_dw):
+    from semseg_amd import segformer as sf
+    monkeypatch.setattr(sf, 'FUSED_DW_MIN_PIXELS', 0 if fused_dw else 1 << 30)     # both depthwise-backward forms on the 16 x 16 .. 2 x 2 maps
     g = np.load(os.path.join(golden_dir, 'mit_b0_64.npz'))
     enc, outs = _run(torch.float32, torch.from_numpy(g['x']))
     for i in range(4):
@@ -42,7 +45,10 @@ def test_mit_b0_fp32_matches_reference_golden(golden_dir):
             assert rel(grads[k[5:]].grad, g[k]) < 1e-4, k
 
 
-def test_mit_b0_bf16_matches_reference_golden(golden_dir):
+@pytest.mark.parametrize('fused_dw', [False, True])
+def test_mit_b0_bf16_matches_reference_golden(golden_dir, monkeypatch, fused_dw):
+    from semseg_amd import segformer as sf
+    monkeypatch.setattr(sf, 'FUSED_DW_MIN_PIXELS', 0 if fused_dw else 1 << 30)
     g = np.load(os.path.join(golden_dir, 'mit_b0_64.npz'))
     enc, outs = _run(torch.bfloat16, torch.from_numpy(g['x']))
     for i in range(4):

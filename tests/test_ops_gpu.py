@@ -201,7 +201,7 @@ def test_colsum(ops, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('B,H,W,C', [(2, 9, 7, 128), (1, 16, 16, 256), (2, 4, 4, 1024), (1, 5, 33, 8)])
+@pytest.mark.parametrize('B,H,W,C', [(2, 9, 7, 128), (1, 16, 16, 256), (2, 4, 4, 1024), (1, 5, 33, 8), (1, 40, 70, 64), (2, 19, 31, 24), (1, 64, 64, 256)])
 def test_dwconv3(ops, dtype, B, H, W, C):
     x, w, b, dy = rnd(B, H, W, C), rnd(C, 1, 3, 3, seed=1) / 3, 0.1 * rnd(C, seed=2), rnd(B, H, W, C, seed=3)
     xr = q(x, dtype).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
@@ -218,6 +218,13 @@ def test_dwconv3(ops, dtype, B, H, W, C):
     assert rel(dx.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _gtol(dtype)
     assert rel(dwdb[:9].t().reshape(C, 1, 3, 3), wr.grad) < _gtol(dtype)
     assert rel(dwdb[9], br.grad) < _gtol(dtype)
+    # the one-pass backward: same gradients without the stored g (strips with halo rows, column tiles with halo columns)
+    dx2, dwdb2 = ops.dwconv3_bwd_fused(dyd, xd, w9c, dev(b), B, H, W, act=1)
+    assert rel(dx2.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _gtol(dtype)
+    assert rel(dwdb2[:9].t().reshape(C, 1, 3, 3), wr.grad) < _gtol(dtype)
+    assert rel(dwdb2[9], br.grad) < _gtol(dtype)
+    if dtype == torch.bfloat16:                         # against the two-pass form: same rounded g, only the summation order differs
+        assert rel(dx2, dx) < 1e-2 and rel(dwdb2, dwdb) < 1e-3
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

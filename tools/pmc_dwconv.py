@@ -1,4 +1,4 @@
-"""dwconv3 fwd (GELU / plain) and bwd launches on the stage-1 MiT-B2 shape, for rocprofv3 --pmc passes."""
+"""dwconv3 fwd (GELU / plain), two-pass bwd and fused bwd launches on the stage-1 MiT-B2 shape, for rocprofv3 --pmc passes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,5 +12,6 @@ for _ in range(2):
     ops.dwconv3_fwd(x, w, b, B, H, W, act=1)
     ops.dwconv3_fwd(x, w, b, B, H, W, act=0)
     ops.dwconv3_bwd(dy, x, w, b, B, H, W, act=1)
+    ops.dwconv3_bwd_fused(dy, x, w, b, B, H, W, act=1)
 torch.cuda.synchronize()
 print('done')
