@@ -9,7 +9,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'semseg_hip.h')
-LIB_PATH = os.path.join(HERE, 'libsemseg_hip.so')
+LIB_PATH = os.environ.get('SEMSEG_HIP_LIB') or os.path.join(HERE, 'libsemseg_hip.so')     # the override serves kernel A/B builds (tools/)
 
 _CTYPES = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'double': ctypes.c_double, 'hipStream_t': ctypes.c_void_p}
 _lib = None

@@ -13,6 +13,15 @@
 // Workgroup = 4 waves x 32 queries (forward, dQ) or 4 x 32 keys (dK/dV); key / query tiles of 64 rows.
 #include "attn_common.h"
 
+// Experiment switch ATTN_PRIO: s_setprio(1) around the matrix-instruction clusters.  Measured null on all four stage shapes
+// (forward and backward within +-1 %), so it is off; tools/attic/README.md has the numbers of this and of the barrier-paced
+// two-halves ("ping-pong") structure, which was 40 % slower.
+#ifndef ATTN_PRIO
+#define ATTN_PRIO 0
+#endif
+#define MFMA_PRIO_UP() do { if (ATTN_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
+#define MFMA_PRIO_DOWN() do { if (ATTN_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+
 // lane-major accumulator (lane = row j of the output, registers = columns) -> bf16 rows through a per-wave LDS image
 template <int D>
 __device__ __forceinline__ void store_rows_bf16(const floatx16 (&acc)[D / 32], float mul, char* img, bf16* dst, int64_t ld, int nrows) {
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* _
         const bool more = key0 + 64 < Nk;
         if (more) gload(key0 + 64);
         floatx16 s[2];
+        MFMA_PRIO_UP();
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -105,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* _
             for (int ks = 0; ks < D / 16; ++ks)
                 s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, img_slot<CH>(kt * 32 + j, ks * 2 + h)), qf[ks], s[kt], 0, 0, 0);
         }
+        MFMA_PRIO_DOWN();
         // online softmax on the raw scores (c > 0 folds scale and log2 e into the exponent's fma); the key-tail mask, the
         // rescale of the output accumulator and nothing else are taken only when a lane needs them (wave-uniform branches)
         if (key0 + 64 > Nk) {
@@ -139,15 +150,21 @@ __global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* _
                 s[kt][r] = p0; s[kt][r + 1] = p1; ps0 += p0; ps1 += p1;
             }
         l += ps0 + ps1;
+        bf16x8 pfr[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) pfr[kt][st] = cvt_frag<bf16>(s[kt], st);
+        MFMA_PRIO_UP();
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                bf16x8 pf = cvt_frag<bf16>(s[kt], st);
 #pragma unroll
                 for (int t = 0; t < D / 32; ++t)
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, PT, kt * 32 + 16 * st, t * 32), pf, oacc[t], 0, 0, 0);
+                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, PT, kt * 32 + 16 * st, t * 32), pfr[kt][st], oacc[t], 0, 0, 0);
             }
+        MFMA_PRIO_DOWN();
         __syncthreads();
         if (more) { lstore(); __syncthreads(); }
     }
@@ -189,7 +206,10 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dq_bf16_kernel(const bf16
     }
     dl += __shfl_xor(dl, 32, 64);
     if (h == 0 && q0 + j < N) delta[(int64_t)(b * heads + hd) * Np + q0 + j] = dl;
-    const float ls = lse[(int64_t)(b * heads + hd) * Np + qrow], dls = dl * scale;
+    // The row constants ride in as the INITIAL accumulators of the two score products (lane = query, so one value per lane):
+    // S' = K.Q^T - lse / c and dP' = V.dO^T - delta leave their MFMA chains ready, P = 2^(S' c) needs no subtraction, dS' = P dP'
+    // one multiply, and the softmax scale is applied once to the finished dQ instead of to every score.
+    const float sinit = -lse[(int64_t)(b * heads + hd) * Np + qrow] / c, dinit = -dl;
     const bf16* kbase = kv + (int64_t)b * Nk * 2 * C + hd * D;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     bf16x8 rk[NCH], rv[NCH];
@@ -228,36 +248,38 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dq_bf16_kernel(const bf16
         for (int kt = 0; kt < 2; ++kt) {
             floatx16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s[r] = sinit; dp[r] = dinit; }
+            MFMA_PRIO_UP();
 #pragma unroll
             for (int ks = 0; ks < D / 16; ++ks) {
                 const int sl = img_slot<CH>(kt * 32 + j, ks * 2 + h);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, sl), qf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, sl), dof[ks], dp, 0, 0, 0);
             }
+            MFMA_PRIO_DOWN();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {                  // dS = P (dP - delta) scale, P = 2^(s c - lse): fma, v_exp, fma, mul
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -ls));
-                s[r] = p * fmaf(dp[r], scale, -dls);
-            }
+            for (int r = 0; r < 16; ++r)                    // dS / scale = P (dP - delta), P = 2^(S' c): mul, v_exp, mul
+                s[r] = __builtin_amdgcn_exp2f(s[r] * c) * dp[r];
             if (key0 + 64 > Nk) {                           // keys past Nk (zero rows of the staged tile) take no part
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (key0 + kt * 32 + acc_row(r, h) >= Nk) s[r] = 0.f;
             }
+            bf16x8 dfr[2] = {cvt_frag<bf16>(s, 0), cvt_frag<bf16>(s, 1)};
+            MFMA_PRIO_UP();
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                bf16x8 df = cvt_frag<bf16>(s, st);
 #pragma unroll
                 for (int t = 0; t < D / 32; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, PT, kt * 32 + 16 * st, t * 32), df, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, PT, kt * 32 + 16 * st, t * 32), dfr[st], acc[t], 0, 0, 0);
             }
+            MFMA_PRIO_DOWN();
         }
         __syncthreads();
         if (more) { lstore(); __syncthreads(); }
     }
     if (q0 < N)
-        store_rows_bf16<D>(acc, 1.f, smem + wave * 32 * (D * 2 + 16), dq + ((int64_t)b * N + q0) * C + hd * D, C, N - q0);
+        store_rows_bf16<D>(acc, scale, smem + wave * 32 * (D * 2 + 16), dq + ((int64_t)b * N + q0) * C + hd * D, C, N - q0);
 }
 
 // ------------------------------------------------------------------ backward: dK, dV (lane = key); fp32 slabs per query split
@@ -265,7 +287,7 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dkv_bf16_kernel(const bf16* __restrict__ q, const bf16* __restrict__ dout,
         const bf16* __restrict__ kv, const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dk_slab,
         float* __restrict__ dv_slab, int B, int N, int Np, int Nk, int Nkp, int heads, int C, float c, float scale, int nsplit,
-        int q_per_split) {
+        int q_per_split, int KB, int ngroups) {
     typedef AttnCfg<D> G;
     constexpr int CH = G::CH, NCH = G::NCH, PT = G::PT;
     constexpr int STG = 2 * G::SW + 2 * G::TR + 512;
@@ -274,8 +296,14 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dkv_bf16_kernel(const bf1
     char* Qs = smem; char* Os = smem + G::SW; char* Qt = smem + 2 * G::SW; char* Ot = Qt + G::TR;
     float* lsd = (float*)(Ot + G::TR);                   // lse[64] | delta[64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z / nsplit, split = blockIdx.z % nsplit, hd = blockIdx.y;
-    const int key0 = (blockIdx.x * 4 + wave) * 32;
+    // the KB key blocks of one (image, split, head) group get block ids 8 apart, i.e. one XCD: Q and dO are fetched from HBM once per
+    // group and re-read from that XCD's L2 by its other key blocks (FETCH_SIZE 2.2 GB -> ~0.3 GB per launch at stage 1; a speed
+    // matter only)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int kb = slot % KB, grp_id = (slot / KB) * 8 + xcd;
+    if (grp_id >= ngroups) return;                        // the group count is padded to a multiple of 8 (before any barrier)
+    const int hd = grp_id % heads, bs = grp_id / heads, split = bs % nsplit, b = bs / nsplit;
+    const int key0 = (kb * 4 + wave) * 32;
     const int krow = min(key0 + j, Nk - 1);
     const bool kvalid = key0 + j < Nk;
     const bf16* kp = kv + ((int64_t)b * Nk + krow) * 2 * C + hd * D;
@@ -289,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dkv_bf16_kernel(const bf1
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     bf16x8 rq[NCH], ro[NCH];
     float rl = 0.f;
+    const float rc = 1.f / c;
     auto gload = [&](int q0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -298,7 +327,8 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dkv_bf16_kernel(const bf1
             rq[i] = ok ? *(const bf16x8*)(qbase + off) : zero;
             ro[i] = ok ? *(const bf16x8*)(obase + off) : zero;
         }
-        if (tid < 128) { const int qq = q0 + (tid & 63); rl = qq < N ? (tid < 64 ? lsep[qq] : dlp[qq]) : 0.f; }
+        // row constants as initial accumulators (see the dQ kernel): -lse / c and -delta per query
+        if (tid < 128) { const int qq = q0 + (tid & 63); rl = qq < N ? (tid < 64 ? -lsep[qq] * rc : -dlp[qq]) : 0.f; }
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -324,29 +354,35 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dkv_bf16_kernel(const bf1
         __syncthreads();
         for (int q0 = qbeg; q0 < qend; q0 += 64) {
             const bool more = q0 + 64 < qend;
-            const bool tail = q0 + 64 > qend || (blockIdx.x + 1) * 128 > Nk;     // workgroup-uniform
+            const bool tail = q0 + 64 > qend || (kb + 1) * 128 > Nk;             // workgroup-uniform
             if (more) gload(q0 + 64);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 floatx16 s, dp;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+                for (int g = 0; g < 4; ++g) {                   // accumulators start at the row constants of their queries
+                    const int ql = qt * 32 + 8 * g + 4 * h;
+                    const floatx4 l4 = *(const floatx4*)(lsd + ql), d4 = *(const floatx4*)(lsd + 64 + ql);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s[4 * g + e] = l4[e]; dp[4 * g + e] = d4[e]; }
+                }
+                MFMA_PRIO_UP();
 #pragma unroll
                 for (int ks = 0; ks < D / 16; ++ks) {
                     const int sl = img_slot<CH>(qt * 32 + j, ks * 2 + h);
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qs, sl), kf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Os, sl), vf[ks], dp, 0, 0, 0);
                 }
+                MFMA_PRIO_DOWN();
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int ql = qt * 32 + 8 * g + 4 * h;
-                    const floatx4 l4 = *(const floatx4*)(lsd + ql), d4 = *(const floatx4*)(lsd + 64 + ql);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < 4; ++e) {                 // P = 2^(S' c), dS / scale = P dP' (the scale goes onto the finished dK)
                         const int r = 4 * g + e;
-                        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -l4[e]));
+                        const float p = __builtin_amdgcn_exp2f(s[r] * c);
                         s[r] = p;
-                        dp[r] = p * (dp[r] - d4[e]) * scale;
+                        dp[r] = p * dp[r];
                     }
                     if (tail) {                                 // keys past Nk, queries past the split (they belong to the next slab; qend <= N)
 #pragma unroll
@@ -354,15 +390,18 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dkv_bf16_kernel(const bf1
                             if (!(kvalid && q0 + ql + e < qend)) { s[4 * g + e] = 0.f; dp[4 * g + e] = 0.f; }
                     }
                 }
+                bf16x8 pfr[2] = {cvt_frag<bf16>(s, 0), cvt_frag<bf16>(s, 1)}, dfr[2] = {cvt_frag<bf16>(dp, 0), cvt_frag<bf16>(dp, 1)};
+                MFMA_PRIO_UP();
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
-                    bf16x8 pf = cvt_frag<bf16>(s, st), df = cvt_frag<bf16>(dp, st);
+                    const bf16x8 pf = pfr[st], df = dfr[st];
 #pragma unroll
                     for (int t = 0; t < D / 32; ++t) {
                         dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, PT, qt * 32 + 16 * st, t * 32), pf, dv[t], 0, 0, 0);
                         dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, PT, qt * 32 + 16 * st, t * 32), df, dk[t], 0, 0, 0);
                     }
                 }
+                MFMA_PRIO_DOWN();
             }
             __syncthreads();
             if (more) { lstore(); __syncthreads(); }
@@ -371,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dkv_bf16_kernel(const bf1
     if (key0 >= Nkp) return;                              // (after every block-wide barrier)
     const int64_t slab = (((int64_t)split * B + b) * heads + hd) * Nkp + key0;
     float* shf = (float*)smem + wave * 32 * (D + 1);
-    store_transposed<float, D>(dk, 1.f, shf, dk_slab + slab * D, D, 32);
+    store_transposed<float, D>(dk, scale, shf, dk_slab + slab * D, D, 32);
     store_transposed<float, D>(dv, 1.f, shf, dv_slab + slab * D, D, 32);
 }
 
@@ -386,11 +425,13 @@ int attn_fwd_bf16_launch(const AttnBf16Args& a, hipStream_t stream) {
     return 0;
 }
 template <int D> static void bwd_launch(const AttnBf16Args& a, hipStream_t st) {
-    dim3 gq((unsigned)cdiv(a.N, 128), a.heads, a.B), gk((unsigned)cdiv(a.Nkp, 128), a.heads, a.B * a.ns);
+    dim3 gq((unsigned)cdiv(a.N, 128), a.heads, a.B);
+    const int KB = (int)cdiv(a.Nkp, 128), ngroups = a.B * a.ns * a.heads;
+    dim3 gk((unsigned)(cdiv(ngroups, 8) * 8 * KB));
     hipLaunchKernelGGL((mit_attn_bwd_dq_bf16_kernel<D>), gq, dim3(256), 0, st, a.q, a.kv, a.dout, a.o, a.lse, a.delta, a.dq, a.N, a.Np, a.Nk,
                        a.heads, a.C, a.c, a.scale);
     hipLaunchKernelGGL((mit_attn_bwd_dkv_bf16_kernel<D>), gk, dim3(256), 0, st, a.q, a.dout, a.kv, a.lse, a.delta, a.dks, a.dvs, a.B, a.N,
-                       a.Np, a.Nk, a.Nkp, a.heads, a.C, a.c, a.scale, a.ns, a.qps);
+                       a.Np, a.Nk, a.Nkp, a.heads, a.C, a.c, a.scale, a.ns, a.qps, KB, ngroups);
 }
 int attn_bwd_bf16_launch(const AttnBf16Args& a, hipStream_t stream) {
     if (a.D == 64) bwd_launch<64>(a, stream); else bwd_launch<32>(a, stream);
