@@ -79,7 +79,7 @@ def entry_work(name, a):
     if name == 'ss_layernorm_fwd':
         return 'hbm', 2.0 * a[7] * a[8] * _sz(a[0])
     if name == 'ss_layernorm_bwd':
-        return 'hbm', (4.0 if a[6] else 3.0) * a[10] * a[11] * _sz(a[0])
+        return 'hbm', (3.0 + (1.0 if a[7] else 0.0) + (1.0 if a[2] else 0.0)) * a[11] * a[12] * _sz(a[0])
     if name == 'ss_dwconv3_fwd':
         return 'hbm', 2.0 * a[5] * a[6] * a[7] * a[8] * _sz(a[0])
     if name == 'ss_dwconv3_bwd':

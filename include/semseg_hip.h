@@ -58,8 +58,9 @@ int ss_gemm_tn_colsum(int dtype, const void* A, int64_t lda, const void* B, int6
 /* ---- nn.LayerNorm over C on token layout (modules/segformer.py:19,30,77,83,90,93,145-198). mean/rstd: [rows] fp32. */
 int ss_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                      float* rstd, int64_t rows, int C, float eps, hipStream_t stream);
-/* dgamma/dbeta: one [2,C] fp32 buffer (dbeta == dgamma + C); workspace >= 1024*2*C floats. */
-int ss_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+/* dgamma/dbeta: one [2,C] fp32 buffer (dbeta == dgamma + C); workspace >= 1024*2*C floats.  dy2: optional second gradient of the same
+ * output, added to dy on the fly (a stage's feature map feeds the head and the next stage, modules/segformer.py:180-198). */
+int ss_layernorm_bwd(int dtype, const void* dy, const void* dy2 /* optional */, const void* x, const float* mean, const float* rstd, const float* gamma,
                      const void* res /* optional [rows,C]: added to dx (gradient of the residual path around the norm) */,
                      void* dx, float* dgamma, float* dbeta, int64_t rows, int C, float* workspace, int64_t ws_bytes,
                      hipStream_t stream);

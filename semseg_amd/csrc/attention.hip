@@ -362,7 +362,7 @@ extern "C" int ss_mit_attn_bwd(int dtype, const void* q, const void* kv, const v
     float* dks = (float*)w; w += (int64_t)ns * B * heads * Nkp * D * 4;
     float* dvs = (float*)w;
     const float c = scale * 1.4426950408889634f;
-    SS_HIP(hipMemsetAsync(delta, 0, (int64_t)B * heads * Np * 4, stream));
+    // (delta needs no clearing: every entry a kernel reads, q < N, is written by the dQ / row-dot kernel before)
     if (dtype == SS_BF16) {
         const int64_t rows = (int64_t)B * N;
         int rb = (int)(cdiv(rows * (C / 8), 256) < 8192 ? cdiv(rows * (C / 8), 256) : 8192);

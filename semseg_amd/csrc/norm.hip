@@ -81,8 +81,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // dx = res + rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat));  per-block partials of dgamma = sum dy*xhat, dbeta = sum dy.
 // `res` (optional) is the gradient arriving over the residual connection around the normalised branch: adding it here saves
 // the separate elementwise pass.  Two rows per lane group are in flight per step; gamma is loaded once per lane.
-template <typename T, int NCH, bool RES>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// `dy2` (optional) is a second gradient of the same output (the output feeds two consumers: a stage's feature map goes to the head
+// AND to the next stage): summed here, in fp32, instead of by a separate elementwise pass.
+template <typename T, int NCH, bool RES, bool DY2>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ x,
         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma, const T* __restrict__ res,
         T* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C, int lpr) {
     extern __shared__ float sh[];                 // [groups][2][C]
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
     for (int64_t r0 = wave * rpw; r0 < rows; r0 += 2 * nwaves * rpw) {
         int64_t r[2]; bool rok[2]; float mu[2], rs[2];
-        Raw8<T> xv[2][NCH], dv[2][NCH], qv[2][NCH];
+        Raw8<T> xv[2][NCH], dv[2][NCH], qv[2][NCH], ev[2][NCH];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             r[u] = r0 + u * nwaves * rpw + lane / lpr;
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 const int c = (lig + j * lpr) * 8, cc = c < C ? c : 0;
                 xv[u][j].load(x + rr * C + cc); dv[u][j].load(dy + rr * C + cc);
                 if (RES) qv[u][j].load(res + rr * C + cc);
+                if (DY2) ev[u][j].load(dy2 + rr * C + cc);
             }
         }
 #pragma unroll
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 const float live = (rok[u] && c < C) ? 1.f : 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float h = (xv[u][j].get(e) - mu[u]) * rs[u], d = dv[u][j].get(e) * live;
+                    const float h = (xv[u][j].get(e) - mu[u]) * rs[u], d = (DY2 ? dv[u][j].get(e) + ev[u][j].get(e) : dv[u][j].get(e)) * live;
                     dg[j][e] = fmaf(d, h, dg[j][e]); db[j][e] += d;
                     const float t = d * gm[j].v[e];
                     xh[j].v[e] = h; gy[j].v[e] = t; s1 += t; s2 = fmaf(t, h, s2);
@@ -185,7 +188,7 @@ extern "C" int ss_layernorm_fwd(int dtype, const void* x, const float* gamma, co
 
 // workspace: SS_LN_BWD_BLOCKS * 2 * C floats
 #define SS_LN_BWD_BLOCKS 1024
-extern "C" int ss_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+extern "C" int ss_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const float* mean, const float* rstd, const float* gamma,
                                 const void* res, void* dx, float* dgamma, float* dbeta, int64_t rows, int C, float* workspace,
                                 int64_t ws_bytes, hipStream_t stream) {
     int lpr, nch;
@@ -196,13 +199,15 @@ extern "C" int ss_layernorm_bwd(int dtype, const void* dy, const void* x, const 
     int blocks = (int)(cdiv(waves, 4) < SS_LN_BWD_BLOCKS ? cdiv(waves, 4) : SS_LN_BWD_BLOCKS);
     SS_CHECK(ws_bytes >= (int64_t)blocks * 2 * C * 4, "ss_layernorm_bwd: workspace too small");
     size_t shm = (size_t)4 * (64 / lpr) * 2 * C * sizeof(float);
-#define SS_LN_BWD(NCH, RES) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, RES>), dim3(blocks), dim3(256), shm, stream, (const T*)dy, (const T*)x, \
+#define SS_LN_BWD(NCH, RES) do { if (dy2) SS_LN_BWD_(NCH, RES, true); else SS_LN_BWD_(NCH, RES, false); } while (0)
+#define SS_LN_BWD_(NCH, RES, DY2) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, RES, DY2>), dim3(blocks), dim3(256), shm, stream, (const T*)dy, (const T*)dy2, (const T*)x, \
         mean, rstd, gamma, (const T*)res, (T*)dx, workspace, rows, C, lpr)
     SS_DISPATCH(dtype, {
         if (nch == 1) { if (res) SS_LN_BWD(1, true); else SS_LN_BWD(1, false); }
         else { if (res) SS_LN_BWD(2, true); else SS_LN_BWD(2, false); }
     });
 #undef SS_LN_BWD
+#undef SS_LN_BWD_
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(2 * C, 8), 1), dim3(256), 0, stream, workspace, blocks, 2 * C, 1.f, dgamma, 0);
     SS_LAUNCH_CHECK();

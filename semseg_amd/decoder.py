@@ -10,7 +10,7 @@ from typing import Sequence
 import torch
 from torch import nn, Tensor
 
-from . import ops
+from . import ops, weightprep
 from .runtime import compute_dtype_for, as_tokens_nhwc
 from .segformer import _ParamFn, w_fwd
 from .lawin import LawinHead, _bn_stats
@@ -58,8 +58,8 @@ class _DecoderTailFn(_ParamFn):
         T = t.dtype
         inc = t.shape[1]
         ld9 = (9 * oc + 7) // 8 * 8
-        wd = torch.zeros((ld9, inc), dtype=T, device=t.device)           # [(o,dy,dx)][c], zero rows pad N to a multiple of 8
-        wd[:9 * oc] = ops.transpose_cast(P['deconvolution.net.0.weight'].detach().reshape(inc, 9 * oc).contiguous(), T)
+        # [(o,dy,dx)][c], zero rows pad N to a multiple of 8: a remembered, batch-refreshed copy (no per-call torch.zeros / slice copy)
+        wd = weightprep.transpose_padded(P['deconvolution.net.0.weight'], inc, 9 * oc, T, ld9)
         wr = w_fwd(P['feature_reducer.net.p_conv.conv.weight'], T)
         z9 = ops.gemm_nt(t, wd)
         bs = ops.gemm_nt(t, wr, bias=P['feature_reducer.net.p_conv.conv.bias'])
@@ -84,8 +84,9 @@ class _DecoderTailFn(_ParamFn):
              'deconvolution.net.1.weight': dgb[:oc], 'deconvolution.net.1.bias': dgb[oc:],
              'feature_reducer.net.p_conv.conv.weight': ops.gemm_tn(dbs, t),
              'feature_reducer.net.p_conv.conv.bias': ops.colsum_any(dbs)}
-        dt = ops.gemm_nt(dz9, ops.transpose_cast(S['wd'].float().contiguous(), T))
-        dt = ops.gemm_nt(dbs, ops.transpose_cast(S['wr'].float().contiguous(), T), res=dt)
+        f32 = (lambda w: w) if T == torch.float32 else (lambda w: ops.cast(w, torch.float32))
+        dt = ops.gemm_nt(dz9, ops.transpose_cast(f32(S['wd']), T))
+        dt = ops.gemm_nt(dbs, ops.transpose_cast(f32(S['wr'].contiguous()), T), res=dt)
         return dt, G
 
 

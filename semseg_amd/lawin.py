@@ -16,7 +16,7 @@ import torch
 from torch import nn, Tensor
 import torch.nn.functional as tnf
 
-from . import ops
+from . import ops, weightprep
 from .runtime import compute_dtype_for, as_tokens_nhwc, deliver_grads, expect_grads
 from .segformer import w_fwd, w_bwd
 from .shapes import LAWIN_BRANCHES
@@ -68,18 +68,20 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     for k, (r, heads) in enumerate(LAWIN_BRANCHES):
         p = f'lawin_{r}'
         G, amax = ops.lawin_pool_fwd(feat, B, H8, W8, r)
-        Wm = torch.stack([P[f'{p}.position_mixing.{i}.weight'].detach() for i in range(heads)]).contiguous()
-        bm = torch.stack([P[f'{p}.position_mixing.{i}.bias'].detach() for i in range(heads)]).contiguous()
+        # operands that the reference builds by looping over / concatenating parameters live in persistent buffers that the
+        # batched weight refresh keeps current (weightprep.gather): no torch.stack / torch.cat in the step
+        Wm = weightprep.gather([P[f'{p}.position_mixing.{i}.weight'] for i in range(heads)], torch.float32).view(heads, 64, 64)
+        bm = weightprep.gather([P[f'{p}.position_mixing.{i}.bias'] for i in range(heads)], torch.float32).view(heads, 64)
         ctx = ops.lawin_mix(Wm, bm, B, H8, W8, r, heads, G=G)
-        wpg = torch.cat([P[f'{p}.phi.weight'].detach().reshape(inter, E), P[f'{p}.g.weight'].detach().reshape(inter, E)])
-        bpg = torch.cat([P[f'{p}.phi.bias'].detach(), P[f'{p}.g.bias'].detach()])
-        pg = ops.gemm_nt(ctx, w_fwd(wpg, T), bias=bpg)
+        wpg = weightprep.gather([P[f'{p}.phi.weight'], P[f'{p}.g.weight']], T).view(2 * inter, E)
+        bpg = weightprep.gather([P[f'{p}.phi.bias'], P[f'{p}.g.bias']], torch.float32)
+        pg = ops.gemm_nt(ctx, wpg, bias=bpg)
         th = ops.gemm_nt(feat, _conv_w(P[f'{p}.theta.weight'], T), bias=P[f'{p}.theta.bias'])
         y, lse = ops.lawin_attn_fwd(th, pg, B, H8, W8, heads)
         z = ops.gemm_nt(y, _conv_w(P[f'{p}.conv_out.0.weight'], T))
         st = _bn_stats(z, P, Bf, f'{p}.conv_out.1', training)
         ops.bn_apply(z, st, P[f'{p}.conv_out.1.weight'], P[f'{p}.conv_out.1.bias'], act=0, res=feat, out=cat5[:, (k + 1) * E:(k + 2) * E])
-        S['br'].append(dict(G=G, amax=amax, Wm=Wm, ctx=ctx, wpg=wpg, pg=pg, th=th, y=y, lse=lse, z=z, st=st))
+        S['br'].append(dict(G=G, amax=amax, Wm=Wm, ctx=ctx, pg=pg, th=th, y=y, lse=lse, z=z, st=st))
 
     # image-pool branch: GAP -> ConvModule -> broadcast (bilinear of a 1x1 map)
     gp = ops.cast(ops.colsum(feat, groups=B, scale=1.0 / (H8 * W8)), T)
@@ -140,9 +142,10 @@ def head_backward(P, S, dseg, E):
     dzp, dgb = ops.bn_bwd(dap, S['zp'], S['stp'], P['image_pool.1.bn.weight'], P['image_pool.1.bn.bias'], act=1, training=training)
     bn_grads('image_pool.1.bn', dgb)
     G['image_pool.1.conv.weight'] = ops.gemm_tn(dzp, S['gp'])
-    dgp = ops.gemm_nt(dzp, w_bwd(P['image_pool.1.conv.weight'], T), out_f32=(T != torch.float32))
-    # gradient fan-in on feat: short path + the three residuals + broadcast of the pooled branch (scaled by 1/(H8*W8))
-    pool_vec = _scaled(dgp, 1.0 / (H8 * W8))
+    # gradient fan-in on feat: short path + the three residuals + broadcast of the pooled branch, whose 1/(H8*W8) rides in the
+    # GEMM epilogue as a row scale
+    pool_vec = ops.gemm_nt(dzp, w_bwd(P['image_pool.1.conv.weight'], T), out_f32=True, rowscale=_const(dzp.device, 1.0 / (H8 * W8)),
+                           rows_per_scale=dzp.shape[0])
     acc = ops.sum_slices(dcat5, 4, E, E, bvec=pool_vec, rows_per_image=H8 * W8)
     dGs, amaxs = [], []
     for k, (r, heads) in enumerate(LAWIN_BRANCHES):
@@ -158,7 +161,8 @@ def head_backward(P, S, dseg, E):
         dwpg, dbpg = ops.gemm_tn(dpg, br['ctx'], colsum=True)
         G[f'{p}.phi.weight'], G[f'{p}.g.weight'] = dwpg[:inter], dwpg[inter:]
         G[f'{p}.phi.bias'], G[f'{p}.g.bias'] = dbpg[:inter], dbpg[inter:]
-        dctxp = ops.gemm_nt(dpg, ops.transpose_cast(br['wpg'].contiguous(), T))
+        wpg32 = weightprep.gather([P[f'{p}.phi.weight'], P[f'{p}.g.weight']], torch.float32).view(2 * inter, E)
+        dctxp = ops.gemm_nt(dpg, ops.transpose_cast(wpg32, T))
         dWb = ops.lawin_mix_wgrad(br['G'], dctxp, B, H8, W8, r, heads)
         for i in range(heads):
             G[f'{p}.position_mixing.{i}.weight'] = dWb[i, :, :64]
@@ -182,9 +186,16 @@ def head_backward(P, S, dseg, E):
     return dt, G
 
 
-def _scaled(v, s):
-    """tiny [B, E] fp32 vector * scalar (host-side plumbing on B*E elements)."""
-    return (v.float() * s).contiguous()
+_CONSTS = {}
+
+
+def _const(device, value):
+    """one-element fp32 device tensor holding `value` (made once per device and value)"""
+    key = (device, float(value))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.full((1,), float(value), dtype=torch.float32, device=device)
+    return t
 
 
 class LawinHeadFn(torch.autograd.Function):

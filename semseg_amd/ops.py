@@ -128,8 +128,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, res=None):
-    """-> dx (+ res, the gradient of the residual path, when given), dgb [2,C] fp32 (dgamma, dbeta)."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, res=None, dy2=None):
+    """-> dx (+ res, the gradient of the residual path, when given), dgb [2,C] fp32 (dgamma, dbeta); dy2: a second gradient of the
+    same output, summed with dy inside the kernel."""
     dev = _dev(x)
     rows, C, ld = _mat(x, 'x')
     if ld != C or dy.shape != x.shape or not dy.is_contiguous() or dy.dtype != x.dtype:
@@ -137,10 +138,12 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, res=None):
     _f32(gamma, 'gamma', C), _f32(mean, 'mean', rows), _f32(rstd, 'rstd', rows)
     if res is not None and (res.shape != x.shape or res.dtype != x.dtype or not res.is_contiguous()):
         raise ValueError('layernorm_bwd: res must be dense and like x')
+    if dy2 is not None and (dy2.shape != x.shape or dy2.dtype != x.dtype or not dy2.is_contiguous()):
+        raise ValueError('layernorm_bwd: dy2 must be dense and like x')
     dx = torch.empty_like(x)
     dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
     ws = workspace(dev, 1024 * 2 * C * 4)
-    check(lib().ss_layernorm_bwd(dt(x), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(res) if res is not None else None, _p(dx), _p(dgb),
+    check(lib().ss_layernorm_bwd(dt(x), _p(dy), _p(dy2) if dy2 is not None else None, _p(x), _p(mean), _p(rstd), _p(gamma), _p(res) if res is not None else None, _p(dx), _p(dgb),
                                  dgb.data_ptr() + C * 4,
                                  rows, C, _p(ws), ws.numel(), _stream()))
     return dx, dgb

@@ -254,6 +254,32 @@ class PatchEmbedFn(_ParamFn):
         return dx, G
 
 
+class StageNormFn(torch.autograd.Function):
+    """A stage's final LayerNorm (modules/segformer.py:180-198).  Its output has two consumers, the head and the next stage's patch
+    embedding, so it is handed out twice (second output = a view of the first): backward then receives the two gradients separately and
+    ``ss_layernorm_bwd`` sums them while it reads them, instead of autograd adding two full feature maps first."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y, m, r = ops.layernorm_fwd(x.detach(), weight, bias, 1e-5)
+        ctx.save_for_backward(x, m, r, weight)
+        ctx.set_materialize_grads(False)                       # an unused output (the last stage has no next stage) arrives as None
+        ctx.params = (weight, bias)
+        expect_grads(ctx, ctx.params, 1)
+        return y, y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy_a, dy_b):
+        x, m, r, weight = ctx.saved_tensors
+        if dy_a is None:
+            dy_a, dy_b = dy_b, None
+        if dy_a is None:
+            return None, None, None
+        dx, dgb = ops.layernorm_bwd(dy_a.contiguous(), x.detach(), m, r, weight, dy2=None if dy_b is None else dy_b.contiguous())
+        gw, gb = deliver_grads(ctx.params, [dgb[0], dgb[1]])
+        return dx, gw, gb
+
+
 class LayerNormFn(_ParamFn):
     @staticmethod
     def fwd(P, x, meta):
@@ -403,7 +429,9 @@ class SegFormer(nn.Module):
             x, h, w = getattr(self, f'patch_embed{s + 1}')(x)
             for blk in getattr(self, f'block{s + 1}'):
                 x = blk(x, h, w)
-            y = LayerNormFn.run(_tokens2d(x), None, getattr(self, f'norm{s + 1}'))
-            x = y.view(b, h, w, -1).permute(0, 3, 1, 2)       # NCHW-shaped view of the channels-last map, as the reference
-            outs.append(x)
+            norm = getattr(self, f'norm{s + 1}')
+            y, y2 = StageNormFn.apply(_tokens2d(x), norm.weight, norm.bias)
+            # NCHW-shaped views of the channels-last map, as the reference: one for the caller, one for the next stage
+            outs.append(y.view(b, h, w, -1).permute(0, 3, 1, 2))
+            x = y2.view(b, h, w, -1).permute(0, 3, 1, 2)
         return tuple(outs)

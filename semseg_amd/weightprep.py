@@ -29,6 +29,7 @@ class _Entry:
 class _DeviceState:
     def __init__(self):
         self.entries, self.order, self.table, self.table_n, self.blocks = {}, [], None, 0, 0
+        self.gathered = {}          # (source pointers, dtype) -> persistent concatenation buffer
 
 
 def bump():
@@ -39,6 +40,7 @@ def bump():
 
 def clear():
     _state.clear()
+    _PADDED.clear()
 
 
 def _refresh(st, device):
@@ -112,6 +114,60 @@ def transpose(p, rows, cols, dtype, reverse_cols=False):
         v = _view2d(p, rows, cols)
         return v, ops.transpose_cast(v, dtype, reverse_cols=reverse_cols), ((1, int(reverse_cols)), rows, cols, 0)
     return _lookup(p, ('tr', rows, cols, dtype, bool(reverse_cols)), make)
+
+
+def gather(params, dtype):
+    """Several parameters laid end to end in ONE persistent buffer of ``dtype`` -- what ``torch.cat`` / ``torch.stack`` of weights gave
+    (modules/lawin.py: the per-head position-mixing Linears as one [heads, 64, 64] operand, phi | g as one projection): each
+    parameter is remembered as a cast whose destination is its slice of the buffer, so the buffer is refreshed by the same batched
+    launch as every other copy and no concatenation runs in the step.  -> flat [sum numel] tensor."""
+    params = list(params)
+    dev = params[0].device
+    if dev.type != 'cuda':
+        raise RuntimeError('semseg_amd: parameters must live on a HIP device (no CPU fallback)')
+    if not all(isinstance(p, nn.Parameter) for p in params):
+        return torch.cat([p.detach().reshape(-1) for p in params]).to(dtype)     # derived tensors (tests): nothing to remember
+    st = _state.get(dev.index)
+    if st is None:
+        st = _state[dev.index] = _DeviceState()
+    key = (tuple(p.data_ptr() for p in params), dtype)
+    buf = st.gathered.get(key)
+    if buf is None:
+        buf = st.gathered[key] = torch.empty(sum(p.numel() for p in params), dtype=dtype, device=dev)
+    off = 0
+    for p in params:
+        n = p.numel()
+
+        def make(p=p, off=off, n=n):
+            v = _view2d(p, 1, n)
+            out = buf[off:off + n]
+            check(lib().ss_cast(0, ops._DT[dtype], v.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream(dev).cuda_stream))
+            return v, out, ((0, 0), 0, 0, 0)
+        _lookup(p, ('gather', dtype, buf.data_ptr(), off), make)
+        off += n
+    return buf
+
+
+_PADDED = {}              # data_ptr of a remembered transpose -> the zero-padded buffer it is the head of
+
+
+def transpose_padded(p, rows, cols, dtype, pad_rows):
+    """``transpose`` whose [cols, rows] result is the head of a persistent [pad_rows, rows] buffer with zero rows behind it (a GEMM
+    operand whose row count must be a multiple of 8: the ConvTranspose2d weight of core/decoder.py as [(o, dy, dx)][c])."""
+    if not isinstance(p, nn.Parameter):
+        full = torch.zeros((pad_rows, rows), dtype=dtype, device=p.device)
+        full[:cols] = ops.transpose_cast(p.detach().reshape(rows, cols).contiguous(), dtype)
+        return full
+
+    def make():
+        v = _view2d(p, rows, cols)
+        full = torch.zeros((pad_rows, rows), dtype=dtype, device=p.device)
+        out = full[:cols]
+        check(lib().ss_transpose_cast(ops._DT[dtype], v.data_ptr(), out.data_ptr(), rows, cols, 0, torch.cuda.current_stream(p.device).cuda_stream))
+        _PADDED[out.data_ptr()] = full
+        return v, out, ((1, 0), rows, cols, 0)
+    out = _lookup(p, ('trp', rows, cols, dtype, pad_rows), make)
+    return _PADDED[out.data_ptr()]
 
 
 def pack(p, dtype, transposed=False):
