@@ -177,6 +177,11 @@ int ss_lawin_pool_fwd(int dtype, const void* feat, int64_t ld, void* G, void* am
 int ss_lawin_pool_bwd(int dtype, const float* dG8, const float* dG4, const float* dG2, const void* amax8, const void* amax4,
                       const void* amax2, const void* base, int64_t ldb, void* dfeat, int64_t ldo, int B, int H, int W, int C,
                       hipStream_t stream);
+/* Stand-alone PatchEmbed.forward (modules/lawin.py:27-35): y [B,ceil(H/ps),ceil(W/ps),C] = 0.5*(max_pool + avg_pool) over ps x ps cells of
+ * x [B,H,W,C] (row stride ldx), zeros beyond the right / bottom edge taking part as F.pad's do; amax: uint8 arg-max position per cell.
+ * ss_patch_pool_bwd: dx [B,H,W,C] from dy and amax (an arg-max that fell on the padding keeps no gradient, as in the reference). */
+int ss_patch_pool_fwd(int dtype, const void* x, int64_t ldx, void* y, void* amax, int B, int H, int W, int C, int ps, hipStream_t stream);
+int ss_patch_pool_bwd(int dtype, const void* dy, const void* amax, void* dx, int B, int H, int W, int C, int ps, hipStream_t stream);
 /* window-ordered d(ctx) [B*nh*nw*64, C] -> dG_r (gather form, deterministic) */
 int ss_lawin_gather_bwd(int dtype, const void* dctx, float* dG, int B, int H, int W, int C, int r, hipStream_t stream);
 /* LawinAttn.position_mixing (:44-46,62-69): out[w,p',c] = x[w,p',c] + sum_p Wm[head(c)][p'][p] x[w,p,c] + bm[head(c)][p'];

@@ -87,6 +87,57 @@ __global__ __launch_bounds__(256) void lawin_pool_bwd_kernel(PoolBwdArgs a, cons
     }
 }
 
+// ------------------------------------------------------------------ stand-alone PatchEmbed (modules/lawin.py:18-35)
+// y[b,oy,ox,:] = 0.5*(max + mean) over the ps x ps cell at (oy*ps, ox*ps); cells that hang over the right / bottom edge see zeros there.
+template <typename T>
+__global__ __launch_bounds__(256) void patch_pool_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
+                                                             unsigned char* __restrict__ amax, int B, int H, int W, int Ho, int Wo, int C, int ps) {
+    const int chunks = C / 8;
+    const int64_t total = (int64_t)B * Ho * Wo * chunks;
+    const float inv = 1.f / (ps * ps);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks) * 8; int64_t p = i / chunks;
+        const int ox = (int)(p % Wo); int64_t q = p / Wo; const int oy = (int)(q % Ho); const int64_t b = q / Ho;
+        float mx[8], sm[8]; int am[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; sm[e] = 0.f; am[e] = 0; }
+        for (int dy = 0; dy < ps; ++dy)
+            for (int dx = 0; dx < ps; ++dx) {
+                const int yy = oy * ps + dy, xx = ox * ps + dx;
+                F8 v = (yy < H && xx < W) ? load8(x + ((b * H + yy) * W + xx) * ldx + c) : zero8();
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sm[e] += v.v[e]; if (v.v[e] > mx[e]) { mx[e] = v.v[e]; am[e] = dy * ps + dx; } }
+            }
+        F8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = 0.5f * (mx[e] + sm[e] * inv);
+        store8(y + p * C + c, o);
+        unsigned long long packed = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) packed |= (unsigned long long)(am[e] & 0xff) << (8 * e);
+        *(unsigned long long*)(amax + p * C + c) = packed;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void patch_pool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ amax,
+                                                             T* __restrict__ dx, int B, int H, int W, int Ho, int Wo, int C, int ps) {
+    const int chunks = C / 8;
+    const int64_t total = (int64_t)B * H * W * chunks;
+    const float w = 0.5f / (ps * ps);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks) * 8; int64_t p = i / chunks;
+        const int xx = (int)(p % W); int64_t q = p / W; const int yy = (int)(q % H); const int64_t b = q / H;
+        const int idx = (yy % ps) * ps + xx % ps;
+        const int64_t cell = ((b * Ho + yy / ps) * Wo + xx / ps) * C + c;
+        F8 d = load8(dy + cell), o;
+        const unsigned long long am = *(const unsigned long long*)(amax + cell);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = d.v[e] * (w + ((int)((am >> (8 * e)) & 0xff) == idx ? 0.5f : 0.f));
+        store8(dx + p * C + c, o);
+    }
+}
+
 // dG[b,gy,gx,:] = sum over the windows (i,j) whose 8x8 cell block contains (gy,gx) of dctx[(b,i,j), (gy-i*st, gx-j*st), :]
 template <typename T>
 __global__ __launch_bounds__(256) void lawin_gather_bwd_kernel(const T* __restrict__ dctx, float* __restrict__ dG, WinGeom g, int C) {
@@ -379,6 +430,27 @@ extern "C" int ss_lawin_pool_bwd(int dtype, const float* dG8, const float* dG4, 
     a.g[0] = win_geom(B, H, W, 8); a.g[1] = win_geom(B, H, W, 4); a.g[2] = win_geom(B, H, W, 2);
     SS_DISPATCH(dtype, hipLaunchKernelGGL((lawin_pool_bwd_kernel<T>), dim3(nblk((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, a,
                                           (const T*)base, ldb, (T*)dfeat, ldo, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ss_patch_pool_fwd(int dtype, const void* x, int64_t ldx, void* y, void* amax, int B, int H, int W, int C, int ps,
+                                 hipStream_t stream) {
+    SS_CHECK(x && y && amax && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldx % 8 == 0 && ps >= 1 && ps <= 16,
+             "ss_patch_pool_fwd: need C %% 8 == 0, 16-byte aligned rows, 1 <= patch_size <= 16 (B=%d H=%d W=%d C=%d ps=%d)", B, H, W, C, ps);
+    const int Ho = (H + ps - 1) / ps, Wo = (W + ps - 1) / ps;
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((patch_pool_fwd_kernel<T>), dim3(nblk((int64_t)B * Ho * Wo * (C / 8))), dim3(256), 0, stream,
+                                          (const T*)x, ldx, (T*)y, (unsigned char*)amax, B, H, W, Ho, Wo, C, ps));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ss_patch_pool_bwd(int dtype, const void* dy, const void* amax, void* dx, int B, int H, int W, int C, int ps, hipStream_t stream) {
+    SS_CHECK(dy && dx && amax && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ps >= 1 && ps <= 16,
+             "ss_patch_pool_bwd: need C %% 8 == 0, 1 <= patch_size <= 16 (B=%d H=%d W=%d C=%d ps=%d)", B, H, W, C, ps);
+    const int Ho = (H + ps - 1) / ps, Wo = (W + ps - 1) / ps;
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((patch_pool_bwd_kernel<T>), dim3(nblk((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream,
+                                          (const T*)dy, (const unsigned char*)amax, (T*)dx, B, H, W, Ho, Wo, C, ps));
     SS_LAUNCH_CHECK();
     return 0;
 }

@@ -14,11 +14,10 @@ Function whose forward and backward are explicit kernel sequences over channels-
 """
 import torch
 from torch import nn, Tensor
-import torch.nn.functional as tnf
 
 from . import ops, weightprep
 from .runtime import compute_dtype_for, as_tokens_nhwc, deliver_grads, expect_grads
-from .segformer import w_fwd, w_bwd
+from .segformer import w_fwd, w_bwd, _sub
 from .shapes import LAWIN_BRANCHES
 
 
@@ -35,6 +34,53 @@ def _bn_stats(z, P, Bf, prefix, training):
 
 def _nchw_view(tok, B, H, W):
     return tok.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def branch_forward(P, Bf, qtok, G, B, H, W, r, heads, E, training, out=None):
+    """LawinAttn.forward (modules/lawin.py:57-94) on token matrices.  qtok: the query map [B*H*W, E] in image order (row stride may
+    exceed E); G: the pooled context grid of ss_lawin_pool_fwd for ratio r -- for a stand-alone call on 8 x 8 windows (H = W = 8) the
+    grid IS the window.  P / Bf: this LawinAttn's parameters / buffers by their own names.  -> (query + BN(conv_out(attention)), state)."""
+    T = qtok.dtype
+    inter = max(E // 2, 1)
+    # operands that the reference builds by looping over / concatenating parameters live in persistent buffers that the
+    # batched weight refresh keeps current (weightprep.gather): no torch.stack / torch.cat in the step
+    Wm = weightprep.gather([P[f'position_mixing.{i}.weight'] for i in range(heads)], torch.float32).view(heads, 64, 64)
+    bm = weightprep.gather([P[f'position_mixing.{i}.bias'] for i in range(heads)], torch.float32).view(heads, 64)
+    ctx = ops.lawin_mix(Wm, bm, B, H, W, r, heads, G=G)
+    wpg = weightprep.gather([P['phi.weight'], P['g.weight']], T).view(2 * inter, E)
+    bpg = weightprep.gather([P['phi.bias'], P['g.bias']], torch.float32)
+    pg = ops.gemm_nt(ctx, wpg, bias=bpg)
+    th = ops.gemm_nt(qtok, _conv_w(P['theta.weight'], T), bias=P['theta.bias'])
+    y, lse = ops.lawin_attn_fwd(th, pg, B, H, W, heads)
+    z = ops.gemm_nt(y, _conv_w(P['conv_out.0.weight'], T))
+    st = _bn_stats(z, P, Bf, 'conv_out.1', training)
+    o = ops.bn_apply(z, st, P['conv_out.1.weight'], P['conv_out.1.bias'], act=0, res=qtok, out=out)
+    return o, dict(G=G, Wm=Wm, ctx=ctx, pg=pg, th=th, y=y, lse=lse, z=z, st=st)
+
+
+def branch_backward(P, br, dout, qtok, acc, B, H, W, r, heads, E, training):
+    """dout: gradient of the branch output [B*H*W, E].  acc: running gradient of the query map (None, or the contributions so far;
+    the residual share `dout` itself is NOT added here).  -> (acc + theta path, dG fp32 [grid rows, E], {param: grad})."""
+    T = dout.dtype
+    inter, G = max(E // 2, 1), {}
+    dz, dgb = ops.bn_bwd(dout, br['z'], br['st'], P['conv_out.1.weight'], P['conv_out.1.bias'], act=0, training=training)
+    G['conv_out.1.weight'], G['conv_out.1.bias'] = dgb[0], dgb[1]
+    G['conv_out.0.weight'] = ops.gemm_tn(dz, br['y'])
+    dy = ops.gemm_nt(dz, w_bwd(P['conv_out.0.weight'], T))
+    dth, dpg = ops.lawin_attn_bwd(br['th'], br['pg'], br['y'], dy, br['lse'], B, H, W, heads)
+    G['theta.weight'], G['theta.bias'] = ops.gemm_tn(dth, qtok, colsum=True)
+    acc = ops.gemm_nt(dth, w_bwd(P['theta.weight'], T), res=acc)
+    dwpg, dbpg = ops.gemm_tn(dpg, br['ctx'], colsum=True)
+    G['phi.weight'], G['g.weight'] = dwpg[:inter], dwpg[inter:]
+    G['phi.bias'], G['g.bias'] = dbpg[:inter], dbpg[inter:]
+    wpg32 = weightprep.gather([P['phi.weight'], P['g.weight']], torch.float32).view(2 * inter, E)
+    dctxp = ops.gemm_nt(dpg, ops.transpose_cast(wpg32, T))
+    dWb = ops.lawin_mix_wgrad(br['G'], dctxp, B, H, W, r, heads)
+    for i in range(heads):
+        G[f'position_mixing.{i}.weight'] = dWb[i, :, :64]
+        G[f'position_mixing.{i}.bias'] = dWb[i, :, 64]
+    dctx = ops.lawin_mix(br['Wm'], None, B, H, W, r, heads, xwin=dctxp, transpose=True)
+    return acc, ops.lawin_gather_bwd(dctx, B, H, W, r), G
 
 
 def head_forward(P, Bf, feats, E, training, drop_mask):
@@ -66,22 +112,11 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     # three large-window attention branches
     S['br'] = []
     for k, (r, heads) in enumerate(LAWIN_BRANCHES):
-        p = f'lawin_{r}'
         G, amax = ops.lawin_pool_fwd(feat, B, H8, W8, r)
-        # operands that the reference builds by looping over / concatenating parameters live in persistent buffers that the
-        # batched weight refresh keeps current (weightprep.gather): no torch.stack / torch.cat in the step
-        Wm = weightprep.gather([P[f'{p}.position_mixing.{i}.weight'] for i in range(heads)], torch.float32).view(heads, 64, 64)
-        bm = weightprep.gather([P[f'{p}.position_mixing.{i}.bias'] for i in range(heads)], torch.float32).view(heads, 64)
-        ctx = ops.lawin_mix(Wm, bm, B, H8, W8, r, heads, G=G)
-        wpg = weightprep.gather([P[f'{p}.phi.weight'], P[f'{p}.g.weight']], T).view(2 * inter, E)
-        bpg = weightprep.gather([P[f'{p}.phi.bias'], P[f'{p}.g.bias']], torch.float32)
-        pg = ops.gemm_nt(ctx, wpg, bias=bpg)
-        th = ops.gemm_nt(feat, _conv_w(P[f'{p}.theta.weight'], T), bias=P[f'{p}.theta.bias'])
-        y, lse = ops.lawin_attn_fwd(th, pg, B, H8, W8, heads)
-        z = ops.gemm_nt(y, _conv_w(P[f'{p}.conv_out.0.weight'], T))
-        st = _bn_stats(z, P, Bf, f'{p}.conv_out.1', training)
-        ops.bn_apply(z, st, P[f'{p}.conv_out.1.weight'], P[f'{p}.conv_out.1.bias'], act=0, res=feat, out=cat5[:, (k + 1) * E:(k + 2) * E])
-        S['br'].append(dict(G=G, amax=amax, Wm=Wm, ctx=ctx, pg=pg, th=th, y=y, lse=lse, z=z, st=st))
+        _, br = branch_forward(_sub(P, f'lawin_{r}.'), _sub(Bf, f'lawin_{r}.'), feat, G, B, H8, W8, r, heads, E, training,
+                               out=cat5[:, (k + 1) * E:(k + 2) * E])
+        br['amax'] = amax
+        S['br'].append(br)
 
     # image-pool branch: GAP -> ConvModule -> broadcast (bilinear of a 1x1 map)
     gp = ops.cast(ops.colsum(feat, groups=B, scale=1.0 / (H8 * W8)), T)
@@ -150,25 +185,9 @@ def head_backward(P, S, dseg, E):
     dGs, amaxs = [], []
     for k, (r, heads) in enumerate(LAWIN_BRANCHES):
         p, br = f'lawin_{r}', S['br'][k]
-        dz, dgb = ops.bn_bwd(dcat5[:, (k + 1) * E:(k + 2) * E], br['z'], br['st'], P[f'{p}.conv_out.1.weight'], P[f'{p}.conv_out.1.bias'],
-                             act=0, training=training)
-        bn_grads(f'{p}.conv_out.1', dgb)
-        G[f'{p}.conv_out.0.weight'] = ops.gemm_tn(dz, br['y'])
-        dy = ops.gemm_nt(dz, w_bwd(P[f'{p}.conv_out.0.weight'], T))
-        dth, dpg = ops.lawin_attn_bwd(br['th'], br['pg'], br['y'], dy, br['lse'], B, H8, W8, heads)
-        G[f'{p}.theta.weight'], G[f'{p}.theta.bias'] = ops.gemm_tn(dth, feat, colsum=True)
-        acc = ops.gemm_nt(dth, w_bwd(P[f'{p}.theta.weight'], T), res=acc)
-        dwpg, dbpg = ops.gemm_tn(dpg, br['ctx'], colsum=True)
-        G[f'{p}.phi.weight'], G[f'{p}.g.weight'] = dwpg[:inter], dwpg[inter:]
-        G[f'{p}.phi.bias'], G[f'{p}.g.bias'] = dbpg[:inter], dbpg[inter:]
-        wpg32 = weightprep.gather([P[f'{p}.phi.weight'], P[f'{p}.g.weight']], torch.float32).view(2 * inter, E)
-        dctxp = ops.gemm_nt(dpg, ops.transpose_cast(wpg32, T))
-        dWb = ops.lawin_mix_wgrad(br['G'], dctxp, B, H8, W8, r, heads)
-        for i in range(heads):
-            G[f'{p}.position_mixing.{i}.weight'] = dWb[i, :, :64]
-            G[f'{p}.position_mixing.{i}.bias'] = dWb[i, :, 64]
-        dctx = ops.lawin_mix(br['Wm'], None, B, H8, W8, r, heads, xwin=dctxp, transpose=True)
-        dGs.append(ops.lawin_gather_bwd(dctx, B, H8, W8, r))
+        acc, dG, Gb = branch_backward(_sub(P, p + '.'), br, dcat5[:, (k + 1) * E:(k + 2) * E], feat, acc, B, H8, W8, r, heads, E, training)
+        G.update({f'{p}.{n}': g for n, g in Gb.items()})
+        dGs.append(dG)
         amaxs.append(br['amax'])
     dfeat = ops.lawin_pool_bwd(dGs, amaxs, B, H8, W8, E, T, base=acc)
     # linear_fuse and the per-level embeddings
@@ -223,6 +242,42 @@ class LawinHeadFn(torch.autograd.Function):
         return (None, None, None, *dfe, *grads)
 
 
+class _LawinFeatsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, names, x, *params):
+        P, Bf = dict(zip(names, params)), dict(module.named_buffers())
+        T, E = compute_dtype_for(x), module.embed_dim
+        B, _, H, W = x.shape
+        feat = as_tokens_nhwc(x.detach(), T)
+        outs, brs = [], []
+        for r, heads in LAWIN_BRANCHES:
+            G, amax = ops.lawin_pool_fwd(feat, B, H, W, r)
+            o, br = branch_forward(_sub(P, f'lawin_{r}.'), _sub(Bf, f'lawin_{r}.'), feat, G, B, H, W, r, heads, E, module.training)
+            br['amax'] = amax
+            outs.append(_nchw_view(o, B, H, W))
+            brs.append(br)
+        ctx.S, ctx.names, ctx.params, ctx.mod, ctx.geom = (feat, brs), names, params, module, (B, H, W)
+        expect_grads(ctx, params, 3)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        (feat, brs), module, (B, H, W) = ctx.S, ctx.mod, ctx.geom
+        P, E, T = dict(zip(ctx.names, ctx.params)), module.embed_dim, feat.dtype
+        d = [as_tokens_nhwc(g, T).contiguous() for g in douts]
+        acc = d[0] + d[1] + d[2]                                   # the three residual paths
+        G, dGs = {}, []
+        for k, (r, heads) in enumerate(LAWIN_BRANCHES):
+            acc, dG, Gb = branch_backward(_sub(P, f'lawin_{r}.'), brs[k], d[k], feat, acc, B, H, W, r, heads, E, module.training)
+            G.update({f'lawin_{r}.{n}': g for n, g in Gb.items()})
+            dGs.append(dG)
+        dfeat = ops.lawin_pool_bwd(dGs, [br['amax'] for br in brs], B, H, W, E, T, base=acc)
+        ctx.S = None
+        grads = [G.get(n) for n in ctx.names]
+        grads = deliver_grads(ctx.params, [g if g is None else g.reshape(p.shape) for g, p in zip(grads, ctx.params)])
+        return (None, None, _nchw_view(dfeat, B, H, W) if ctx.needs_input_grad[2] else None, *grads)
+
+
 # ------------------------------------------------------------------ modules (reference API)
 class MLP(nn.Module):
     def __init__(self, dim=2048, embed_dim=768):
@@ -245,9 +300,25 @@ class MLP(nn.Module):
         return _Fn.run(as_tokens_nhwc(x, compute_dtype_for(x)), None, self).view(b, h * w, -1)
 
 
+class _PatchPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ps):
+        b, c, h, w = x.shape
+        T = compute_dtype_for(x)
+        y, amax = ops.patch_pool_fwd(as_tokens_nhwc(x.detach(), T), b, h, w, ps)
+        ctx.amax, ctx.geom, ctx.T = amax, (b, h, w, ps), T
+        return _nchw_view(y, b, -(-h // ps), -(-w // ps))
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, h, w, ps = ctx.geom
+        dx = ops.patch_pool_bwd(as_tokens_nhwc(dy, ctx.T).contiguous(), ctx.amax, b, h, w, ps)
+        return _nchw_view(dx, b, h, w), None
+
+
 class PatchEmbed(nn.Module):
-    """0.5 * (max_pool + avg_pool) with right/bottom zero padding (modules/lawin.py:18-35).  API-compatibility module:
-    LawinHead never calls it (its pooled-context kernel subsumes it); standalone calls use torch pooling."""
+    """0.5 * (max_pool + avg_pool) with right/bottom zero padding (modules/lawin.py:18-35) on ss_patch_pool_fwd / _bwd.
+    LawinHead.forward itself never calls it: its pooled-context grid (ss_lawin_pool_fwd) subsumes the three ds_r modules."""
 
     def __init__(self, patch_size=4) -> None:
         super().__init__()
@@ -255,16 +326,42 @@ class PatchEmbed(nn.Module):
         self.proj = nn.ModuleList([nn.MaxPool2d(patch_size, patch_size), nn.AvgPool2d(patch_size, patch_size)])
 
     def forward(self, x: Tensor) -> Tensor:
-        _, _, h, w = x.shape
-        if w % self.patch_size != 0:
-            x = tnf.pad(x, (0, self.patch_size - w % self.patch_size))
-        if h % self.patch_size != 0:
-            x = tnf.pad(x, (0, 0, 0, self.patch_size - h % self.patch_size))
-        return 0.5 * (self.proj[0](x) + self.proj[1](x))
+        if x.shape[1] % 8:
+            raise ValueError('PatchEmbed: channels must be a multiple of 8 on the MI355X path')
+        return _PatchPoolFn.apply(x, self.patch_size)
+
+
+class _LawinAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, names, query, context, *params):
+        P, Bf = dict(zip(names, params)), dict(module.named_buffers())
+        T = compute_dtype_for(query)
+        bw, E = query.shape[0], query.shape[1]
+        q, c = as_tokens_nhwc(query.detach(), T), as_tokens_nhwc(context.detach(), T).contiguous()
+        # each 8 x 8 window is an "image" of one window: its pooled grid is the context window itself (any ratio)
+        o, br = branch_forward(P, Bf, q, c, bw, 8, 8, 8, module.head, E, module.training)
+        ctx.S, ctx.names, ctx.params, ctx.mod = (q, br), names, params, module
+        expect_grads(ctx, params, 4)
+        return _nchw_view(o, bw, 8, 8)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (q, br), module = ctx.S, ctx.mod
+        P = dict(zip(ctx.names, ctx.params))
+        bw, E, T = q.shape[0] // 64, q.shape[1], q.dtype
+        d = as_tokens_nhwc(dout, T).contiguous()
+        dq, dG, G = branch_backward(P, br, d, q, d, bw, 8, 8, 8, module.head, E, module.training)
+        ctx.S = None
+        grads = [G.get(n) for n in ctx.names]
+        grads = deliver_grads(ctx.params, [g if g is None else g.reshape(p.shape) for g, p in zip(grads, ctx.params)])
+        return (None, None, _nchw_view(dq, bw, 8, 8) if ctx.needs_input_grad[2] else None,
+                _nchw_view(ops.cast(dG, T), bw, 8, 8) if ctx.needs_input_grad[3] else None, *grads)
 
 
 class LawinAttn(nn.Module):
-    """Parameter container with the reference layout (modules/lawin.py:39-55); computed inside LawinHeadFn."""
+    """modules/lawin.py:39-94: per-head position mixing of the context, theta / phi / g 1x1 convs, per-head softmax attention over the
+    64 positions, conv_out (1x1 + BatchNorm2d), + query.  Inside LawinHead.forward the same kernel sequence runs on the whole map
+    (branch_forward); forward() here is the reference's stand-alone call on window batches [windows, C, 8, 8]."""
 
     def __init__(self, in_ch=512, head=4, patch_size=8, reduction=2) -> None:
         super().__init__()
@@ -275,6 +372,16 @@ class LawinAttn(nn.Module):
         self.theta = nn.Conv2d(in_ch, self.inter_channels, (1, 1))
         self.phi = nn.Conv2d(in_ch, self.inter_channels, (1, 1))
         self.conv_out = nn.Sequential(nn.Conv2d(self.inter_channels, in_ch, (1, 1), bias=False), nn.BatchNorm2d(in_ch))
+        self.patch_size, self.in_ch = patch_size, in_ch
+
+    def forward(self, query: Tensor, context: Tensor) -> Tensor:
+        if query.shape != context.shape or tuple(query.shape[1:]) != (self.in_ch, 8, 8) or self.patch_size != 8:
+            raise ValueError(f'LawinAttn: query and context must both be [windows, {self.in_ch}, 8, 8] (position mixing is Linear(64, 64)); '
+                             f'got {tuple(query.shape)} and {tuple(context.shape)}')
+        if self.in_ch % (2 * self.head) or (self.in_ch // 2) % 8:
+            raise ValueError('LawinAttn: in_ch / 2 must be a multiple of 8 and of the head count on the MI355X path')
+        names = [n for n, _ in self.named_parameters()]
+        return _LawinAttnFn.apply(self, names, query, context, *[p for _, p in self.named_parameters()])
 
 
 class ConvModule(nn.Module):
@@ -332,6 +439,18 @@ class LawinHead(nn.Module):
             return None
         noise = torch.empty((b, self.embed_dim, 1, 1), dtype=dtype, device=device).bernoulli_(1 - p).div_(1 - p)   # as F.dropout2d
         return noise.float().reshape(b, self.embed_dim).contiguous()
+
+    def get_lawin_att_feats(self, x: Tensor, patch_size: int):
+        """modules/lawin.py:140-179: the three large-window attention maps [lawin_8, lawin_4, lawin_2](x), each [B, C, H, W].  The
+        unfold / pool / fold of the reference is the pooled-grid gather of ss_lawin_pool_fwd; only patch_size 8 exists (position
+        mixing is Linear(64, 64) in the reference too)."""
+        if patch_size != 8:
+            raise ValueError('LawinHead.get_lawin_att_feats: patch_size must be 8 (LawinAttn.position_mixing is Linear(64, 64))')
+        _, c, h, w = x.shape
+        if c != self.embed_dim or h % 8 or w % 8:
+            raise ValueError(f'LawinHead.get_lawin_att_feats: need [B, {self.embed_dim}, 8k, 8l], got {tuple(x.shape)}')
+        named = [(n, p) for n, p in self.named_parameters() if n.startswith('lawin_')]
+        return list(_LawinFeatsFn.apply(self, [n for n, _ in named], x, *[p for _, p in named]))
 
     def forward(self, features):
         x1, x2, x3, x4 = features

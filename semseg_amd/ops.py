@@ -493,6 +493,30 @@ def lawin_pool_bwd(dGs, amaxs, B, H, W, C, dtype, base=None):
     return out
 
 
+def patch_pool_fwd(x, B, H, W, ps):
+    """x [B*H*W, C] (row stride ld) -> y [B*ceil(H/ps)*ceil(W/ps), C] = 0.5*(max + avg) pooling with zero right/bottom padding, amax uint8."""
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    if rows != B * H * W:
+        raise ValueError('patch_pool_fwd: bad x')
+    n = B * (-(-H // ps)) * (-(-W // ps))
+    y = torch.empty((n, C), dtype=x.dtype, device=dev)
+    amax = torch.empty((n, C), dtype=torch.uint8, device=dev)
+    check(lib().ss_patch_pool_fwd(dt(x), _p(x), ld, _p(y), _p(amax), B, H, W, C, ps, _stream()))
+    return y, amax
+
+
+def patch_pool_bwd(dy, amax, B, H, W, ps):
+    dev = _dev(dy)
+    rows, C, ld = _mat(dy, 'dy')
+    n = B * (-(-H // ps)) * (-(-W // ps))
+    if rows != n or ld != C or amax.dtype != torch.uint8 or amax.shape != (n, C) or not amax.is_contiguous():
+        raise ValueError('patch_pool_bwd: bad dy / amax')
+    dx = torch.empty((B * H * W, C), dtype=dy.dtype, device=dev)
+    check(lib().ss_patch_pool_bwd(dt(dy), _p(dy), _p(amax), _p(dx), B, H, W, C, ps, _stream()))
+    return dx
+
+
 def lawin_gather_bwd(dctx, B, H, W, r):
     dev = _dev(dctx)
     nwin = B * (H // 8) * (W // 8)
