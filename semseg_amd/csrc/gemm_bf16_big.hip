@@ -120,6 +120,142 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(FastGemm p) {
     }
 }
 
+// LDS-DMA by hand for the persistent kernel.  hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of any LDS access once an
+// LDS-DMA builtin is in flight (it cannot tell the stages apart), which would make every k-iteration wait for the prefetch it has
+// just issued; instructions it does not see are waited for by the kernel itself.  M0 (the LDS destination) is written right before
+// each use and nothing else in the kernel reads it.
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(lds_void*)p; }
+__device__ __forceinline__ void dma_b128(const void* g, unsigned lds_uniform) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(lds_uniform) : "memory");
+}
+__device__ __forceinline__ void dma_b32(const void* g, unsigned lds_uniform) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_uniform) : "memory");
+}
+
+// Persistent form: one workgroup per CU walks a run of tiles of its XCD.  The last k-iteration of a tile already issues the first
+// k-tile of the NEXT tile into the free stage, and the epilogue is per wave through 4 KiB of LDS of its own (nt_epilogue_wave), so
+// a tile's drain (bias / activation / residual, 128 KiB of stores) overlaps the next tile's fill instead of an idle chip; no
+// workgroup ever waits for the launch of its successor.
+__global__ __launch_bounds__(512) void gemm_nt_bf16_256p_kernel(FastGemm p, int ntiles, int pfd) {
+    constexpr int BK = 64;
+    constexpr int IMG = 256 * BK * 2;
+    constexpr int STAGE = 2 * IMG;
+    // three arrays, so that alias analysis keeps the compiler's own LDS-DMA waits (vmcnt(0) before an LDS access that may alias a
+    // fill in flight) away from the epilogue and from the prefetch target
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(1024))) char epi[8 * 2048];
+    __shared__ __attribute__((aligned(256))) char pfl[8 * 256];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int nk = (int)(p.K / BK);
+    // tiles of XCD x (blocks x, x + 8, ... share its L2): a contiguous run, walked by the XCD's workgroups side by side
+    const int x = blockIdx.x & 7, s = blockIdx.x >> 3, S = gridDim.x >> 3;
+    const int q = ntiles >> 3, r8 = ntiles & 7;
+    const int cnt = q + (x < r8 ? 1 : 0), start = x < r8 ? x * (q + 1) : r8 * (q + 1) + (x - r8) * q;
+    if (s >= cnt) return;
+
+    const bf16* pa[4]; const bf16* pb[4];
+    auto setptr = [&](int tile) {
+        const int64_t m0 = (int64_t)(tile / p.ntn) * 256;
+        const int n0 = (tile % p.ntn) * 256;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                   // recomputed per tile: hoisted, the eight 64-bit row offsets were spilled
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int R = (wave * 4 + i) * 4 + (ln >> 4);
+            const int xx = (ln & 15) ^ (R & 15);
+            const int row = 2 * R + (xx >> 3), ch = (xx & 7) * 8;
+            int64_t ra = m0 + row; if (ra >= p.M) ra = p.M - 1;
+            pa[i] = p.A + ra * p.lda + ch;
+            pb[i] = p.B + (int64_t)(n0 + row) * p.ldb + ch;
+        }
+    };
+    const unsigned stage_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 4096);
+    const unsigned pf_lds = __builtin_amdgcn_readfirstlane(lds_addr(pfl) + wave * 256);
+    auto issue = [&](int stage, int kt) {
+        const unsigned st = stage_lds + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_b128(pa[i] + kt * BK, st + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_b128(pb[i] + kt * BK, st + IMG + i * 1024);
+    };
+
+    // L2 prefetch of the activation operand, PFD k-tiles ahead of the fills: one 4-byte load per lane and k-iteration touches both
+    // 64-byte halves of the 256 rows' next 128-byte segments.  A fill that finds its lines in L2 completes in ~0.6 us instead of the
+    // ~2.5 us of an HBM round trip, and with ONE k-tile in flight per workgroup that round trip was the k-iteration (39 % of the MFMA
+    // rate at any K).  The value goes nowhere (an LDS-DMA dword per lane into 256 bytes nobody reads: no register to keep alive); loads
+    // return in order and the iteration top waits for all but the newest vector-memory operation -- that prefetch.
+    int pf_t = s, pf_kt = 0;
+    const int pf_row = tid >> 1, pf_half = (tid & 1) * 32;
+    const bf16* pf_base;
+    auto pf_settile = [&](int t) {
+        int64_t ra = (int64_t)((start + t) / p.ntn) * 256 + pf_row; if (ra >= p.M) ra = p.M - 1;
+        pf_base = p.A + ra * p.lda + pf_half;
+    };
+    auto prefetch = [&]() {
+        dma_b32(pf_base + pf_kt * BK, pf_lds);
+    };
+    auto pf_advance = [&]() {
+        if (pf_kt + 1 < nk) ++pf_kt;
+        else if (pf_t + S < cnt) { pf_t += S; pf_kt = 0; pf_settile(pf_t); }
+    };
+    pf_settile(s);
+    for (int d = 0; d < pfd; ++d) { pf_advance(); prefetch(); }
+    setptr(start + s);
+    issue(0, 0);
+    prefetch();
+    int it = 0;
+    for (int t = s; t < cnt; t += S) {
+        const int tile = start + t;
+        const int64_t m0 = (int64_t)(tile / p.ntn) * 256;
+        const int n0 = (tile % p.ntn) * 256;
+        floatx16 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt, ++it) {
+            // k-tile `it` has landed (everything but the newest prefetch is complete) and nobody still reads the other stage.  A bare
+            // s_barrier: __syncthreads() carries a release fence, i.e. vmcnt(0), which would wait for the prefetch's HBM round trip
+            asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+            const bool last = kt + 1 == nk;
+            if (!last) issue((it + 1) & 1, kt + 1);
+            else if (t + S < cnt) { setptr(tile + S); issue((it + 1) & 1, 0); }
+            if (!last || t + S < cnt) { pf_advance(); prefetch(); }
+            const bf16* As = (const bf16*)(smem + (it & 1) * STAGE);
+            const bf16* Bs = (const bf16*)(smem + (it & 1) * STAGE + IMG);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 fa[2], fb[4];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) fa[a] = *(const bf16x8*)(As + big_slot(wm * 64 + a * 32 + li, ks * 2 + lh) * 8);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) fb[b] = *(const bf16x8*)(Bs + big_slot(wn * 128 + b * 32 + li, ks * 2 + lh) * 8);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
+            }
+        }
+        nt_epilogue_wave<2, 4>(acc, p, epi + wave * 2048, m0, n0, wm * 64, wn * 128, lane);
+    }
+}
+
+static int cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
+        n = v & ~7;
+    }
+    return n;
+}
+
 bool ss_big_nt_ok(const FastGemm& p) {
     // MFMA-bound shapes only: enough k-tiles to amortise the tile's fill and drain, whole 256-column tiles, a full chip
     if (p.K % 64 || p.K < 256 || p.N % 256) return false;
@@ -127,8 +263,20 @@ bool ss_big_nt_ok(const FastGemm& p) {
 }
 
 int ss_big_nt_launch(FastGemm p, hipStream_t st) {
+    static int mode = -1;                                  // SS_GEMM_BIG: 1 = one tile per workgroup, anything else = persistent
+    if (mode < 0) { const char* e = getenv("SS_GEMM_BIG"); mode = e && e[0] == '1' ? 1 : 2; }
     { const char* e = getenv("SS_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.ntn = p.N / 256;
+    const int ntiles = (int)(p.ntn * cdiv(p.M, 256));
+    // measured inside the training step (not in isolation): the persistent form wins 4-11 % where a CU walks >= 4 tiles of a
+    // multi-column-tile output with a short k-loop, and loses up to 10 % on single-column-tile, one-tile-per-CU or long-K launches
+    if (mode == 2 && ntiles >= 4 * cu_count() && p.N >= 512 && p.K <= 1024) {
+        static int pfd = -1;                               // prefetch distance in k-tiles (SS_GEMM_PFD; measured: 0 .. 5 all within 1 %)
+        if (pfd < 0) { const char* e = getenv("SS_GEMM_PFD"); pfd = e ? atoi(e) : 2; if (pfd < 0 || pfd > 16) pfd = 2; }
+        hipLaunchKernelGGL(gemm_nt_bf16_256p_kernel, dim3((unsigned)cu_count()), dim3(512), 0, st, p, ntiles, pfd);
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(gemm_nt_bf16_256_kernel, dim3((unsigned)(p.ntn * cdiv(p.M, 256))), dim3(512), 0, st, p);
     SS_LAUNCH_CHECK();
     return 0;

@@ -104,3 +104,83 @@ __device__ __forceinline__ void nt_epilogue_dispatch(floatx16 (&acc)[TA][TB], co
     }
 #undef SS_EPI
 }
+
+// Per-WAVE epilogue of the persistent NT kernels: no workgroup barrier and no tile-sized LDS image, so the operand stages stay free
+// for the next tile's fills while this tile drains.  A wave turns its TA x TB accumulators into C through 2 KiB of LDS of its own,
+// one 32 x 32 accumulator tile at a time: the lane (output row li, 4 consecutive columns per register quad) writes 8-byte cells, the
+// tile is read back as 16-byte chunks with 4 lanes along a row, and leaves as 64-byte row segments (the neighbouring tile completes
+// the 128-byte line a few instructions later).  8-byte cell q of row r sits at q ^ (((r >> 2) & 3) << 1): cell pairs stay adjacent
+// for the 16-byte reads, rows that share banks spread over the bank pairs.  The residual (and the pre-activation of act 6) is read
+// in the accumulator layout (8 bytes per lane; the reads that share a line follow each other and hit in L1); bias / activation /
+// row scale / residual are applied in fp32 before the one rounding, as in nt_epilogue_cells.
+template <int ACT, bool RES, int TA, int TB>
+__device__ __forceinline__ void nt_epilogue_wave_cells(floatx16 (&acc)[TA][TB], const FastGemm& p, char* wl, int64_t m0, int n0,
+                                                       int mbase, int nbase, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int wsw = ((li >> 2) & 3) << 1;
+    const int rr = lane >> 2, c16 = lane & 3;
+    bf16* C = (bf16*)p.C;
+#pragma unroll
+    for (int a = 0; a < TA; ++a) {
+        const int64_t m = m0 + mbase + a * 32 + li;
+        const bool mok = m < p.M;
+        float rs = 1.f;
+        if (p.rowscale && mok) rs = p.rowscale[m / p.rows_per_scale];
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + nbase + b * 32 + 8 * g + 4 * lh;
+                floatx4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bv = *(const floatx4*)(p.bias + n);
+                bf16x4 rv = {0, 0, 0, 0};
+                if (RES && mok) rv = *(const bf16x4*)(p.res + m * p.ldr + n);
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[a][b][4 * g + e] + bv[e];
+                    if (ACT == 6) v = v * rs * gelu_erf_grad((float)rv[e]);
+                    else { v = apply_act(v, ACT); v = RES ? v * rs + (float)rv[e] : v * rs; }
+                    o[e] = (bf16)v;
+                }
+                *(bf16x4*)(wl + li * 64 + (((2 * g + lh) ^ wsw) << 3)) = o;
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = j * 16 + rr;
+                const bf16x8 v = *(const bf16x8*)(wl + r * 64 + ((c16 ^ ((r >> 2) & 3)) << 4));
+                const int64_t row = m0 + mbase + a * 32 + r;
+                if (row < p.M) nt_store_chunk(p, C, row, n0 + nbase + b * 32 + c16 * 8, v);
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
+template <int TA, int TB>
+__device__ __forceinline__ void nt_epilogue_wave(floatx16 (&acc)[TA][TB], const FastGemm& p, char* wl, int64_t m0, int n0, int mbase,
+                                                 int nbase, int lane) {
+#define SS_EPW(ACT, RES) nt_epilogue_wave_cells<ACT, RES, TA, TB>(acc, p, wl, m0, n0, mbase, nbase, lane)
+    if (p.res) {
+        switch (p.act) {
+            case 1: SS_EPW(1, true); break;
+            case 2: SS_EPW(2, true); break;
+            case 3: SS_EPW(3, true); break;
+            case 4: SS_EPW(4, true); break;
+            case 5: SS_EPW(5, true); break;
+            case 6: SS_EPW(6, true); break;
+            default: SS_EPW(0, true); break;
+        }
+    } else {
+        switch (p.act) {
+            case 1: SS_EPW(1, false); break;
+            case 2: SS_EPW(2, false); break;
+            case 3: SS_EPW(3, false); break;
+            case 4: SS_EPW(4, false); break;
+            case 5: SS_EPW(5, false); break;
+            default: SS_EPW(0, false); break;
+        }
+    }
+#undef SS_EPW
+}

@@ -64,6 +64,7 @@ def test_gemm_nt(ops, dtype, M, N, K):
 @pytest.mark.parametrize('M,N,K', [(1000, 64, 64), (777, 128, 128), (4099, 320, 320), (513, 512, 560), (260, 1280, 320), (300, 48 + 512, 512),
                                    (2050, 256, 2560), (129, 576, 152), (640, 8, 64), (1003, 512, 6), (77, 1032, 8),
                                    (65536 + 77, 256, 256), (33000, 512, 320), (17000, 1024, 576),      # 256 x 256 tile kernel
+                                   (131072 + 77, 512, 256), (65536 + 300, 1280, 320),                 # its persistent form (>= 4 tiles per CU)
                                    (65536 + 5, 256, 96), (131072, 128, 64), (70000, 256, 32 * 11), (33000, 512, 128)])   # long-M shapes of the 128 tile kernel
 def test_gemm_nt_bf16_fast_path(ops, M, N, K):
     """shapes that take the 128 x {64,128} x 64 bf16 kernels: ragged M, K tails (K % 64 != 0), N tails, bias + GELU + DropPath row
@@ -453,7 +454,7 @@ def test_dwconvk_weight_gradient(ops, dtype, k, C, H, W):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('M,N,K', [(1000, 384, 96), (70000, 768, 192), (513, 96, 384)])
+@pytest.mark.parametrize('M,N,K', [(1000, 384, 96), (70000, 768, 192), (513, 96, 384), (131072 + 5, 512, 256)])
 def test_gemm_nt_gelu_gradient_epilogue(ops, dtype, M, N, K):
     """act 6: (A . B^T) * GELU'(res), the GELU backward of modules/convnext.py:43-45 inside the data-gradient GEMM."""
     a, b, z = rnd(M, K), rnd(N, K, seed=1) / math.sqrt(K), rnd(M, N, seed=2) * 2
@@ -468,7 +469,7 @@ def test_gemm_nt_gelu_gradient_epilogue(ops, dtype, M, N, K):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize('shape', [(4096, 384, 96), (1000, 768, 192), (640, 3072, 768), (130, 24, 16)])
+@pytest.mark.parametrize('shape', [(4096, 384, 96), (1000, 768, 192), (640, 3072, 768), (130, 24, 16), (131072 + 40, 512, 256)])
 def test_gemm_nt_gelu2_equals_gemm_then_gelu(dtype, shape):
     """Linear + GELU with both outputs from one epilogue == the GEMM followed by the GELU kernel, bit for bit (every tile kernel)."""
     from semseg_amd import ops
