@@ -234,10 +234,221 @@ __global__ __launch_bounds__(128) void lawin_attn_bwd_mfma_kernel(LawinAttnArgs 
     }
 }
 
+// ------------------------------------------------------------------ head dims 2 / 4 / 8: a wave takes a GROUP of 16 / DH heads
+// The 16 channels of a head group are one MFMA k-step.  Per head the query-side fragment (theta, dY) keeps only that head's
+// channels (zeroed dwords: DH >= 2 channels = whole dwords), so S and dP come out per head from fragments loaded once per group;
+// the products that end in channels (O = P g, dtheta, dphi, dg) mask the channel-side operand by LANE (the transposed image
+// fragment has lane = channel; lanes 16..31 read image columns nobody filled and are always masked) and accumulate all heads of the group into ONE tile, normalised per channel at the store.
+// (On the vector ALU this op needed ~13 instructions per (query, key) pair and head; here the pair costs the softmax only.)
+template <int DH> struct GrpCfg { static constexpr int G = 16 / DH, PT = 64, IMG = 64 * PT; };
+
+template <int DH>
+__device__ __forceinline__ bf16x8 head_channels(const bf16x8& f, int hh, int h) {     // lane half h holds channels 8h .. 8h+7
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    u4 v = __builtin_bit_cast(u4, f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = ((8 * h + 2 * i) / DH == hh) ? v[i] : 0u;
+    return __builtin_bit_cast(bf16x8, v);
+}
+template <int DH>
+__device__ __forceinline__ bf16x8 head_lanes(const bf16x8& f, int hh, int li) {        // lane li = channel li of the group (>= 16: padding)
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    u4 v = __builtin_bit_cast(u4, f);
+    const bool keep = li / DH == hh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = keep ? v[i] : 0u;
+    return __builtin_bit_cast(bf16x8, v);
+}
+// rows 0..15 of a lane-major accumulator tile -> 8-byte pieces (channels 8g + 4h .. +3, g = 0, 1), each channel times mul[its head]
+template <int DH>
+__device__ __forceinline__ void store_group_row(const floatx16& acc, const float (&mul)[16 / DH], int h, bf16* rowp) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        bf16x4 v;                                       // both candidates, then a select: a select of the INDEX sends mul[] to scratch
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = acc[4 * g + e] * mul[(8 * g + e) / DH], hi = acc[4 * g + e] * mul[(8 * g + 4 + e) / DH];
+            v[e] = (bf16)(h ? hi : lo);
+        }
+        *(bf16x4*)(rowp + 8 * g + 4 * h) = v;
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(128) void lawin_attn_fwd_grp_kernel(LawinAttnArgs a) {
+    typedef GrpCfg<DH> C;
+    constexpr int G = C::G, PT = C::PT;
+    __shared__ __attribute__((aligned(16))) char smem[2 * C::IMG];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int groups = a.heads / G;
+    const int64_t idx = (int64_t)blockIdx.x * 2 + wave;
+    if (idx >= a.nwin * groups) return;
+    const int64_t wi = idx / groups; const int gp = (int)(idx % groups);
+    char* Vt = smem + wave * C::IMG;
+    const bf16* pgw = a.pg + wi * 64 * 2 * (int64_t)a.inter + gp * 16;
+    fill_image<16>(Vt, [&](int r) { return pgw + (int64_t)r * 2 * a.inter + a.inter; });
+    bf16x8 qf[2], kf[2];
+    int64_t qrow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        qrow[t] = win_row(a, wi, t * 32 + j);
+        qf[t] = *(const bf16x8*)(a.theta + qrow[t] * a.ldt + gp * 16 + 8 * h);
+        kf[t] = *(const bf16x8*)(pgw + (int64_t)(t * 32 + j) * 2 * a.inter + 8 * h);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        floatx16 oacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+        float linv[G];
+#pragma unroll
+        for (int hh = 0; hh < G; ++hh) {
+            const bf16x8 qm = head_channels<DH>(qf[qt], hh, h);
+            floatx16 s[2];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt], qm, s[kt], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.c2;
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], a.c2, -mx)); s[kt][r] = p; l += p; }
+            l += __shfl_xor(l, 32, 64);
+            linv[hh] = 1.f / l;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(head_lanes<DH>(tr_frag(Vt, PT, kt * 32 + 16 * st, 0), hh, j), cvt_frag<bf16>(s[kt], st),
+                                                                   oacc, 0, 0, 0);
+            if (h == 0) a.lse_out[(wi * a.heads + gp * G + hh) * 64 + qt * 32 + j] = mx + log2f(l);
+        }
+        store_group_row<DH>(oacc, linv, h, a.out + qrow[qt] * a.ldy + gp * 16);
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(128) void lawin_attn_bwd_grp_kernel(LawinAttnArgs a) {
+    typedef GrpCfg<DH> C;
+    constexpr int G = C::G, PT = C::PT;
+    constexpr int PER_WAVE = 2 * C::IMG + G * 512;
+    __shared__ __attribute__((aligned(16))) char smem[2 * PER_WAVE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int groups = a.heads / G;
+    const int64_t idx = (int64_t)blockIdx.x * 2 + wave;
+    if (idx >= a.nwin * groups) return;
+    const int64_t wi = idx / groups; const int gp = (int)(idx % groups);
+    char* R0 = smem + wave * PER_WAVE; char* R1 = R0 + C::IMG; float* lsd = (float*)(R1 + C::IMG);     // [G][ lse[64] | delta[64] ]
+    const bf16* pgw = a.pg + wi * 64 * 2 * (int64_t)a.inter + gp * 16;
+    fill_image<16>(R0, [&](int r) { return pgw + (int64_t)r * 2 * a.inter; });                               // phi
+    fill_image<16>(R1, [&](int r) { return a.dy + win_row(a, wi, r) * a.lddy + gp * 16; });                  // dY
+    bf16x8 qf[2], dof[2], kf[2], vf[2];
+    int64_t qrow[2]; float ls[2][G], dl[2][G];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        qrow[t] = win_row(a, wi, t * 32 + j);
+        const int co = gp * 16 + 8 * h;
+        qf[t] = *(const bf16x8*)(a.theta + qrow[t] * a.ldt + co);
+        dof[t] = *(const bf16x8*)(a.dy + qrow[t] * a.lddy + co);
+        const bf16x8 of = *(const bf16x8*)(a.y + qrow[t] * a.ldy + co);
+        kf[t] = *(const bf16x8*)(pgw + (int64_t)(t * 32 + j) * 2 * a.inter + 8 * h);
+        vf[t] = *(const bf16x8*)(pgw + (int64_t)(t * 32 + j) * 2 * a.inter + a.inter + 8 * h);
+#pragma unroll
+        for (int hh = 0; hh < G; ++hh) {
+            float dot = 0.f;                             // this lane half's share of head hh (zero when the head lives in the other half)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dot += ((8 * h + e) / DH == hh) ? (float)dof[t][e] * (float)of[e] : 0.f;
+            dl[t][hh] = (dot + __shfl_xor(dot, 32, 64)) * a.scale;
+            ls[t][hh] = a.lse[(wi * a.heads + gp * G + hh) * 64 + t * 32 + j];
+            if (h == 0) { lsd[hh * 128 + t * 32 + j] = ls[t][hh]; lsd[hh * 128 + 64 + t * 32 + j] = dl[t][hh]; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float one[G];
+#pragma unroll
+    for (int hh = 0; hh < G; ++hh) one[hh] = 1.f;
+    // ---- pass 1, lane = query: dtheta_q = scale * sum_k P (dP - delta) phi_k
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < G; ++hh) {
+            const bf16x8 qm = head_channels<DH>(qf[qt], hh, h), dom = head_channels<DH>(dof[qt], hh, h);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                floatx16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt], qm, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt], dom, dp, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], a.c2, -ls[qt][hh])) * fmaf(dp[r], a.scale, -dl[qt][hh]);
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(head_lanes<DH>(tr_frag(R0, PT, kt * 32 + 16 * st, 0), hh, j), cvt_frag<bf16>(s, st),
+                                                                  acc, 0, 0, 0);
+            }
+        }
+        store_group_row<DH>(acc, one, h, a.dtheta + qrow[qt] * a.lddt + gp * 16);
+    }
+    // ---- pass 2, lane = key: dg_k = sum_q P dY_q ; dphi_k = scale * sum_q P (dP - delta_q) theta_q
+    __builtin_amdgcn_wave_barrier();
+    fill_image<16>(R0, [&](int r) { return a.theta + win_row(a, wi, r) * a.ldt + gp * 16; });               // theta (columns 16..31 stay zero)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        floatx16 dk, dv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int hh = 0; hh < G; ++hh) {
+                floatx16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(head_channels<DH>(qf[qt], hh, h), kf[kt], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(head_channels<DH>(dof[qt], hh, h), vf[kt], dp, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ql = qt * 32 + 8 * g + 4 * h;
+                    const floatx4 l4 = *(const floatx4*)(lsd + hh * 128 + ql), d4 = *(const floatx4*)(lsd + hh * 128 + 64 + ql);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], a.c2, -l4[e]));
+                        s[r] = p;
+                        dp[r] = p * fmaf(dp[r], a.scale, -d4[e]);
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const bf16x8 pf = cvt_frag<bf16>(s, st), df = cvt_frag<bf16>(dp, st);
+                    dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(head_lanes<DH>(tr_frag(R1, PT, qt * 32 + 16 * st, 0), hh, j), pf, dv, 0, 0, 0);
+                    dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(head_lanes<DH>(tr_frag(R0, PT, qt * 32 + 16 * st, 0), hh, j), df, dk, 0, 0, 0);
+                }
+            }
+        bf16* drow = a.dpg + (wi * 64 + kt * 32 + j) * 2 * (int64_t)a.inter + gp * 16;
+        store_group_row<DH>(dk, one, h, drow);
+        store_group_row<DH>(dv, one, h, drow + a.inter);
+    }
+}
+
 // ------------------------------------------------------------------ host side (called from lawin.hip)
 bool lawin_attn_mfma_ok(int D, const void* theta, int64_t ldt, const void* pg, int inter, const void* p2, int64_t ld2, const void* p3,
                         int64_t ld3, const void* p4, int64_t ld4) {
-    if (!(D == 16 || D == 32 || D == 64) || inter % 8 || ldt % 8 || !aligned16(theta) || !aligned16(pg)) return false;
+    const bool grouped = (D == 2 || D == 4 || D == 8) && inter % 16 == 0;        // 16 / D heads per wave
+    if (!(D == 16 || D == 32 || D == 64 || grouped) || inter % 8 || ldt % 8 || !aligned16(theta) || !aligned16(pg)) return false;
     if (p2 && (ld2 % 8 || !aligned16(p2))) return false;
     if (p3 && (ld3 % 8 || !aligned16(p3))) return false;
     if (p4 && (ld4 % 8 || !aligned16(p4))) return false;
@@ -251,6 +462,14 @@ int lawin_attn_fwd_mfma(const void* theta, int64_t ldt, const void* pg, void* y,
     a.H = H; a.W = W; a.nh = H / 8; a.nw = W / 8; a.inter = inter; a.heads = heads; a.nwin = (int64_t)B * a.nh * a.nw;
     a.scale = 1.f / sqrtf((float)D); a.c2 = a.scale * 1.4426950408889634f;
     const unsigned blocks = (unsigned)cdiv(a.nwin * heads, 2);
+    if (D <= 8) {
+        const unsigned gb = (unsigned)cdiv(a.nwin * (heads / (16 / D)), 2);
+        if (D == 8) hipLaunchKernelGGL(lawin_attn_fwd_grp_kernel<8>, dim3(gb), dim3(128), 0, stream, a);
+        else if (D == 4) hipLaunchKernelGGL(lawin_attn_fwd_grp_kernel<4>, dim3(gb), dim3(128), 0, stream, a);
+        else hipLaunchKernelGGL(lawin_attn_fwd_grp_kernel<2>, dim3(gb), dim3(128), 0, stream, a);
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
     if (D == 64) hipLaunchKernelGGL(lawin_attn_fwd_mfma_kernel<64>, dim3(blocks), dim3(128), 0, stream, a);
     else if (D == 32) hipLaunchKernelGGL(lawin_attn_fwd_mfma_kernel<32>, dim3(blocks), dim3(128), 0, stream, a);
     else hipLaunchKernelGGL(lawin_attn_fwd_mfma_kernel<16>, dim3(blocks), dim3(128), 0, stream, a);
@@ -266,6 +485,14 @@ int lawin_attn_bwd_mfma(const void* theta, int64_t ldt, const void* pg, const vo
     a.H = H; a.W = W; a.nh = H / 8; a.nw = W / 8; a.inter = inter; a.heads = heads; a.nwin = (int64_t)B * a.nh * a.nw;
     a.scale = 1.f / sqrtf((float)D); a.c2 = a.scale * 1.4426950408889634f;
     const unsigned blocks = (unsigned)cdiv(a.nwin * heads, 2);
+    if (D <= 8) {
+        const unsigned gb = (unsigned)cdiv(a.nwin * (heads / (16 / D)), 2);
+        if (D == 8) hipLaunchKernelGGL(lawin_attn_bwd_grp_kernel<8>, dim3(gb), dim3(128), 0, stream, a);
+        else if (D == 4) hipLaunchKernelGGL(lawin_attn_bwd_grp_kernel<4>, dim3(gb), dim3(128), 0, stream, a);
+        else hipLaunchKernelGGL(lawin_attn_bwd_grp_kernel<2>, dim3(gb), dim3(128), 0, stream, a);
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
     if (D == 64) hipLaunchKernelGGL(lawin_attn_bwd_mfma_kernel<64>, dim3(blocks), dim3(128), 0, stream, a);
     else if (D == 32) hipLaunchKernelGGL(lawin_attn_bwd_mfma_kernel<32>, dim3(blocks), dim3(128), 0, stream, a);
     else hipLaunchKernelGGL(lawin_attn_bwd_mfma_kernel<16>, dim3(blocks), dim3(128), 0, stream, a);

@@ -336,10 +336,12 @@ def test_small_helpers(ops):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('B,H,W,inter,heads', [(2, 16, 24, 64, 4), (1, 8, 16, 128, 4), (2, 16, 16, 128, 2), (1, 16, 8, 32, 8), (1, 8, 8, 64, 64)])
+@pytest.mark.parametrize('B,H,W,inter,heads', [(2, 16, 24, 64, 4), (1, 8, 16, 128, 4), (2, 16, 16, 128, 2), (1, 16, 8, 32, 8), (1, 8, 8, 64, 64),
+                                               (2, 16, 16, 256, 64), (1, 16, 8, 128, 64), (1, 8, 16, 128, 16), (1, 8, 8, 48, 12), (1, 8, 8, 40, 10)])
 def test_lawin_window_attention(ops, dtype, B, H, W, inter, heads):
-    """per (8x8 window, head) softmax(theta phi^T / sqrt(d)) g (modules/lawin.py:72-91) and its backward; head dims 16/32/64 take
-    the MFMA kernels in bf16, the others (and fp32) the vector-ALU kernels."""
+    """per (8x8 window, head) softmax(theta phi^T / sqrt(d)) g (modules/lawin.py:72-91) and its backward; in bf16 head dims 16/32/64
+    take the one-head-per-wave MFMA kernels and 2/4/8 (embed 512: 64 heads of 4; embed 256: 64 heads of 2, 16 of 8) the grouped ones
+    (16 channels = 16/d heads per wave); the rest (d = 1, inter % 16 != 0) and fp32 the vector-ALU kernels."""
     d = inter // heads
     nh, nw = H // 8, W // 8
     nwin = B * nh * nw
