@@ -116,7 +116,38 @@ def entry_work(name, a):
         return 'hbm', 1.0 * B * H * W * (2 * C * _sz(a[0]) + 8 + 4)
     if name == 'ss_adabound_step':
         return 'hbm', 28.0 * a[4]
+    if name == 'ss_dwconv3_bwd_fused':
+        return 'hbm', 3.0 * a[7] * a[8] * a[9] * a[10] * _sz(a[0])
+    if name == 'ss_rowscale':
+        return 'hbm', 2.0 * a[5] * a[6] * _sz(a[0])
+    if name in ('ss_lawin_attn_fwd', 'ss_lawin_attn_bwd'):          # window attention: HBM-bound at these head dims (64 keys per window)
+        B, H, W, inter = (a[7:11] if name.endswith('fwd') else a[12:16])
+        rows = B * H * W
+        return 'hbm', (4.0 if name.endswith('fwd') else 8.0) * rows * inter * _sz(a[0])   # theta, phi|g, y  (+ dy, dtheta, dphi|dg)
+    if name == 'ss_lawin_mix':
+        B, H, W, C = a[6:10]
+        return 'hbm', 2.0 * B * H * W * C * _sz(a[0])
+    if name == 'ss_lawin_mix_wgrad':
+        B, H, W, C = a[4:8]
+        return 'hbm', 2.0 * B * H * W * C * _sz(a[0])
     return 'hbm', None
+
+
+def entry_bytes(name, a):
+    """algorithmic HBM bytes (every operand touched once) of the matrix-core entry points, for the per-launch roofline max(flops, bytes)."""
+    if name == 'ss_gemm_nt':
+        M, N, K = a[8:11]
+        return (M * K + N * K + M * N * (2 if a[12] else 1)) * _sz(a[0])
+    if name in ('ss_gemm_tn', 'ss_gemm_tn_colsum'):
+        M, N, K = a[7:10]
+        return (K * M + K * N) * _sz(a[0]) + M * N * 4
+    if name == 'ss_mit_attn_fwd':
+        B, N, Nk, h, D = a[5:10]
+        return (2.0 * B * N * h * D + 2.0 * B * Nk * h * D) * _sz(a[0])            # q, out; k, v
+    if name == 'ss_mit_attn_bwd':
+        B, N, Nk, h, D = a[8:13]
+        return (4.0 * B * N * h * D + 4.0 * B * Nk * h * D) * _sz(a[0])            # q, o, do, dq; kv, dkv
+    return None
 
 
 def kernel_table(trace):
@@ -128,18 +159,12 @@ def kernel_table(trace):
         t = tab.setdefault(name, {'calls': 0, 'ms': 0.0, 'work': 0.0, 'bound': bound, 'known': True, 'bytes': 0.0, 'ideal_ms': 0.0})
         t['calls'] += 1
         t['ms'] += ms
-        if name.startswith('ss_gemm') and work is not None:
-            # algorithmic bytes (every operand touched once) and the roofline time of THIS shape: most launches of the family
-            # are projections with K, N of a few hundred, bounded by HBM rather than by the matrix cores
-            a = args
-            if name == 'ss_gemm_nt':
-                M, N, K = a[8:11]
-                byt = (M * K + N * K + M * N * (2 if a[12] else 1)) * _sz(a[0])
-            else:
-                M, N, K = a[7:10]
-                byt = (K * M + K * N) * _sz(a[0]) + M * N * 4
-            t['bytes'] += byt
-            t['ideal_ms'] += 1e3 * max(work / (MFMA_BF16_PEAK_TFLOPS * 1e12), byt / (HBM_PEAK_GBS * 1e9))
+        if work is not None:
+            # roofline time of THIS launch: max(flops / MFMA peak, algorithmic bytes / HBM peak) -- most GEMM launches are projections
+            # with K, N of a few hundred, bounded by HBM rather than by the matrix cores
+            byt = entry_bytes(name, args) if bound == 'mfma' else work
+            t['bytes'] += byt or 0.0
+            t['ideal_ms'] += 1e3 * max(work / (MFMA_BF16_PEAK_TFLOPS * 1e12) if bound == 'mfma' else 0.0, (byt or 0.0) / (HBM_PEAK_GBS * 1e9))
         if work is None:
             t['known'] = False
         else:
@@ -179,20 +204,40 @@ def shape_table(trace):
               f"{fl / per / 1e9:7.1f} TFLOP/s {byt / per / 1e6:7.0f} GB/s", file=sys.stderr)
 
 
-def roofline_from_table(tab, traffic_ok=False):
+FAMILIES = (('gemm', ('ss_gemm',)), ('mit_attention', ('ss_mit_attn',)), ('depthwise_conv', ('ss_dwconv',)), ('batchnorm', ('ss_bn_',)),
+            ('layernorm', ('ss_layernorm',)), ('lawin_window_attention', ('ss_lawin',)), ('resample', ('ss_bilinear', 'ss_im2col', 'ss_col2im')),
+            ('loss_metrics', ('ss_ohem', 'ss_dice', 'ss_confusion', 'ss_label_hist')), ('optimizer', ('ss_adabound',)))
+
+
+def family_of(name):
+    for fam, prefixes in FAMILIES:
+        if name.startswith(prefixes):
+            return fam
+    return 'other'
+
+
+def family_table(tab):
     fam = {}
     for name, t in tab.items():
-        key = 'gemm' if name.startswith('ss_gemm') else name
-        f = fam.setdefault(key, {'calls': 0, 'ms': 0.0, 'work': 0.0, 'bound': t['bound'], 'known': True, 'bytes': 0.0, 'ideal_ms': 0.0})
-        for k in ('calls', 'ms', 'work', 'bytes', 'ideal_ms'):
+        f = fam.setdefault(family_of(name), {'calls': 0, 'ms': 0.0, 'work': 0.0, 'bound': t['bound'], 'known_ms': 0.0, 'bytes': 0.0, 'ideal_ms': 0.0})
+        for k in ('calls', 'ms', 'bytes', 'ideal_ms'):
             f[k] += t.get(k, 0.0)
-        f['known'] = f['known'] and t['known']
+        if t['known']:
+            f['work'] += t['work']
+            f['known_ms'] += t['ms']
+        if t['bound'] == 'mfma':
+            f['bound'] = 'mfma'
+    return fam
+
+
+def roofline_from_table(tab, traffic_ok=False):
+    fam = family_table(tab)
+    total = sum(t['ms'] for t in tab.values())
     name, f = max(fam.items(), key=lambda kv: kv[1]['ms'])
     out = {'kernel': 'gemm_kernel (ss_gemm_nt + ss_gemm_tn)' if name == 'gemm' else name, 'bound': f['bound'],
-           'launches_per_step': f['calls'], 'avg_launch_us': 1e3 * f['ms'] / f['calls'],
-           'step_share': f['ms'] / sum(t['ms'] for t in tab.values())}
-    if f['known'] and f['ms'] > 0:
-        per_s = f['work'] / (f['ms'] * 1e-3)
+           'launches_per_step': f['calls'], 'avg_launch_us': 1e3 * f['ms'] / f['calls'], 'step_share': f['ms'] / total}
+    if f['known_ms'] > 0:
+        per_s = f['work'] / (f['known_ms'] * 1e-3)
         if f['bound'] == 'mfma':
             out.update(achieved=per_s / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s')
         else:
@@ -201,16 +246,32 @@ def roofline_from_table(tab, traffic_ok=False):
     else:
         out.update(achieved=None, peak=None, unit=None, frac=None)
     out['traffic'] = None
-    if name == 'gemm' and f['ideal_ms'] > 0:
+    if f['ideal_ms'] > 0:
         # per-launch roofline: sum over launches of max(flops / MFMA peak, algorithmic bytes / HBM peak), over the measured time
         out['algorithmic_bytes_per_launch'] = f['bytes'] / f['calls']
         out['frac_of_per_shape_roofline'] = f['ideal_ms'] / f['ms']
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_hbm_traffic.json')
+    if name == 'gemm':
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_hbm_traffic.json')
         if traffic_ok and os.path.exists(pmc):
             with open(pmc) as fh:
                 g = json.load(fh)['gemm_family']
             out['traffic'] = g['hbm_bytes_per_launch']
-            out['traffic_source'] = 'profiles/r01_pmc_hbm_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this command)'
+            out['traffic_source'] = 'profiles/r02_pmc_hbm_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this command, tools/profile_pmc.sh)'
+    # the five families with the largest share, each against its own bound: `frac` = achieved / peak of the bound it is priced on,
+    # `frac_of_per_launch_roofline` = sum of the launches' max(flops / MFMA peak, bytes / HBM peak) over the measured time
+    top = []
+    for fname, ff in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])[:5]:
+        e = {'family': fname, 'ms': ff['ms'], 'share': ff['ms'] / total, 'launches': ff['calls'], 'bound': ff['bound']}
+        if ff['known_ms'] > 0:
+            per_s = ff['work'] / (ff['known_ms'] * 1e-3)
+            e['frac'] = per_s / (MFMA_BF16_PEAK_TFLOPS * 1e12 if ff['bound'] == 'mfma' else HBM_PEAK_GBS * 1e9)
+            e['frac_of_per_launch_roofline'] = ff['ideal_ms'] / ff['known_ms'] if ff['ideal_ms'] > 0 else None
+        top.append(e)
+    out['families'] = top
+    # what the step would take if every launch with a known work formula ran at its roofline (the rest is carried at its measured time)
+    known_ms = sum(t['ms'] for t in tab.values() if t['known'])
+    out['model_roofline_ms'] = sum(t['ideal_ms'] for t in tab.values() if t['known']) + (total - known_ms)
+    out['model_roofline_coverage'] = known_ms / total
     return out
 
 
@@ -377,7 +438,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     cm = met.compute()                                           # int64 confusion-matrix all-reduce (C2)
-    roof, table = None, None
+    roof, table, comm = None, None, None
+    if world > 1:                                                # one more step with the bucket all-reduces timed on their stream
+        reducer.time_comm = True
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        step_ms = 1e3 * (time.perf_counter() - t1)
+        reducer.time_comm = False
+        c = torch.tensor([reducer.comm_ms(), step_ms], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(c, op=dist.ReduceOp.MAX)
+        comm = {'world_size': dist.get_world_size(), 'backend': dist.get_backend(), 'allreduce_ms_per_step': float(c[0]),
+                'allreduce_share_of_step': float(c[0] / c[1]), 'buckets': len(reducer.buckets),
+                'note': 'sum of the bucket all-reduce durations on the communication stream (they overlap the backward), max over ranks, '
+                        'over the wall time of that step'}
     if not a.no_roofline:                                        # every rank runs the extra step (it contains collectives)
         _lib.TRACE = []
         step()
@@ -407,6 +482,8 @@ def main():
            'loss': float(loss.detach()), 'mIoU': float(cm['mIoU']), 'peak_mem_gib': torch.cuda.max_memory_allocated() / 2 ** 30}
     if roof is not None:
         res['roofline'] = roof
+    if comm is not None:
+        res['communicator'] = comm
     if table is not None:                                        # the rate with the optimizer step excluded, beside `value`
         opt_ms = sum(t['ms'] for name, t in table.items() if 'adabound' in name)
         res['optimizer_ms_per_step'] = opt_ms
