@@ -292,6 +292,61 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
     } else dst[0] = from_f<T>(accumulate ? to_f(dst[0]) + acc[0] : acc[0]);
 }
 
+// Narrow tensors (the nc-class logits, C <= 8) up-sampled by an integer factor S: a thread owns ALL channels of one input pixel and
+// gathers its 2S x 2S output taps in fully unrolled, branch-free loops (independent loads; clamped addresses, zero weights outside).
+// Output ox = S*ix + j, j in [-S/2, 3S/2): its source coordinate sits t = (j + 0.5)/S - 0.5 from ix and weighs 1 - |t|; at the
+// borders the clamped taps of torch's formula fold the overhang onto the edge pixel (weight 1).  bf16 channel pairs are 4-byte loads.
+// grid: (B*hi rows, blocks of 256 px)
+template <typename T, int S>
+__global__ __launch_bounds__(256) void bilinear_bwd_narrow_kernel(const T* __restrict__ dy, int64_t ldy, T* __restrict__ dx, int64_t ldx,
+        int hi, int wi, int C, int accumulate, int pairs) {
+    const unsigned row = blockIdx.x, b = row / (unsigned)hi;
+    const int iy = (int)(row - b * hi);
+    const int ix = (int)(blockIdx.y * 256u + threadIdx.x);
+    if (ix >= wi) return;
+    const int ho = hi * S, wo = wi * S;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    auto weight = [](int j, int i, int n) {              // tap j of input index i on an axis of n inputs
+        const float t = (j + 0.5f) / S - 0.5f;
+        float w = 1.f - fabsf(t);
+        if ((i == 0 && t < 0.f) || (i == n - 1 && t > 0.f)) w = 1.f;
+        const int o = S * i + j;
+        return (o >= 0 && o < n * S) ? w : 0.f;
+    };
+#pragma unroll
+    for (int jy = -S / 2; jy < S + S / 2; ++jy) {
+        const float wy = weight(jy, iy, hi);
+        const int oy = min(max(S * iy + jy, 0), ho - 1);
+        const T* srow = dy + (((int64_t)b * ho + oy) * wo) * ldy;
+#pragma unroll
+        for (int jx = -S / 2; jx < S + S / 2; ++jx) {
+            const float w = wy * weight(jx, ix, wi);
+            const int ox = min(max(S * ix + jx, 0), wo - 1);
+            const T* src = srow + (int64_t)ox * ldy;
+            if (pairs) {
+                const unsigned* p2 = (const unsigned*)src;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (2 * e < C) {
+                        const unsigned u = p2[e];
+                        acc[2 * e] = fmaf(w, __uint_as_float(u << 16), acc[2 * e]);
+                        acc[2 * e + 1] = fmaf(w, __uint_as_float(u & 0xffff0000u), acc[2 * e + 1]);
+                    }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < C) acc[e] = fmaf(w, to_f(src[e]), acc[e]);
+            }
+        }
+    }
+    T* dst = dx + ((int64_t)row * wi + ix) * ldx;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (e < C) dst[e] = from_f<T>(accumulate ? to_f(dst[e]) + acc[e] : acc[e]);
+}
+
 extern "C" int ss_bilinear_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
                                hipStream_t stream) {
     SS_CHECK(x && y && B > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && C > 0 && ldx >= C && ldy >= C, "ss_bilinear_fwd: bad arguments");
@@ -335,6 +390,16 @@ extern "C" int ss_bilinear_bwd(int dtype, const void* dy, int64_t ldy, void* dx,
     const int chunks = vec ? C / 8 : C;
     const int64_t per_row = (int64_t)wi * chunks;
     SS_CHECK(per_row < (1LL << 31) && cdiv(per_row, 256) < 65536 && (int64_t)B * hi < (1LL << 31), "ss_bilinear_bwd: row too long");
+    if (!vec && C <= 8 && ho == wo / wi * hi && wo % wi == 0 && (wo / wi == 2 || wo / wi == 4)) {
+        const int pairs = dtype == SS_BF16 && C % 2 == 0 && ldy % 2 == 0 && ((uintptr_t)dy & 3) == 0;
+        dim3 grid((unsigned)(B * hi), (unsigned)cdiv(wi, 256));
+        SS_DISPATCH(dtype, {
+            if (wo / wi == 4) hipLaunchKernelGGL((bilinear_bwd_narrow_kernel<T, 4>), grid, dim3(256), 0, stream, (const T*)dy, ldy, (T*)dx, ldx, hi, wi, C, accumulate, pairs);
+            else hipLaunchKernelGGL((bilinear_bwd_narrow_kernel<T, 2>), grid, dim3(256), 0, stream, (const T*)dy, ldy, (T*)dx, ldx, hi, wi, C, accumulate, pairs);
+        });
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid((unsigned)(B * hi), (unsigned)cdiv(per_row, 256));
     SS_DISPATCH(dtype, {
         if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)dy, ldy, (T*)dx, ldx, hi, wi, ho, wo, fast_div(chunks), accumulate);
