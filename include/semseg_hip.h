@@ -270,6 +270,19 @@ int ss_stage_image_u8(int out_dtype, const uint8_t* src, const float* mu, const 
                       int64_t oh, int64_t ow, int B, int C, int H, int W, hipStream_t stream);
 int ss_stage_label_u8(const uint8_t* src, int64_t* out, int64_t n, hipStream_t stream);
 
+/* ---- geometric augmentation on the device (data_factory/transforms.py:168-475; train.py:69-113: hflip, vflip, RandomAffine,
+ * RandomPerspective, all NEAREST).  Planes [planes][H][W] dense of elem_bytes-sized elements (1, 2, 4, 8: uint8 images, bf16 / fp32
+ * images, int64 labels -- nearest sampling moves elements, no arithmetic); src must not alias dst.
+ * ss_warp_nearest: kind 0 = affine, coef[k] = 8 floats per transform on the DEVICE holding torchvision's inverse matrix
+ *   [m0 m1 m2 m3 m4 m5 - -]; kind 1 = perspective, the 8 coefficients of its _get_perspective_coeffs.  Plane p uses transform
+ *   p / (planes / nxform).  Output pixel -> source by the float32 grid of torchvision's tensor path and grid_sample(nearest, zeros,
+ *   align_corners=False); pixels whose source falls outside take fill_host[p % nfill] (bit patterns, read on the HOST at launch;
+ *   nfill = 0: zeros).  torchvision is not vendored in the reference: parity unpinned, checked against oracle/augment.py.
+ * ss_flip: horizontal != 0 mirrors x (hflip), else y (vflip). */
+int ss_warp_nearest(int kind, int elem_bytes, const void* src, void* dst, int planes, int H, int W, const float* coef, int nxform,
+                    const uint64_t* fill_host, int nfill, hipStream_t stream);
+int ss_flip(int elem_bytes, const void* src, void* dst, int planes, int H, int W, int horizontal, hipStream_t stream);
+
 /* ---- core/decoder.py:49-59 tail on channels-last maps.  x = LawinHead output [B,H4,W4,2oc].  The host runs two GEMMs on x:
  * z9 [rows, ld9 >= 9*oc] = x . Wd (ConvTranspose2d k3 s4 weight as [(o,dy,dx)][c], modules/blocks.py:224-234) and bs [rows, oc] =
  * conv1x1(x) + b (feature_reducer, core/decoder.py:38-47; the 1x1 conv commutes with the nearest up-sampling of :52-58).

@@ -753,6 +753,45 @@ def stage_image(src, mu, sigma, dtype, channels_last):
     return out
 
 
+def _planes(x, who):
+    if not x.is_cuda:
+        raise RuntimeError('semseg_amd: tensors must live on a HIP device (no CPU fallback)')
+    if x.dim() < 2 or not x.is_contiguous() or x.element_size() not in (1, 2, 4, 8):
+        raise ValueError(f'{who}: need a contiguous [..., H, W] tensor of 1/2/4/8-byte elements')
+    H, W = x.shape[-2:]
+    P = x.numel() // (H * W) if H * W else 0
+    if P == 0 or P > 65535 or H > 65535:
+        raise ValueError(f'{who}: empty tensor, or more than 65535 planes / rows')
+    return P, H, W
+
+
+def flip(x, horizontal):
+    """[..., H, W] -> mirrored along W (horizontal) or H; any 1/2/4/8-byte dtype, bit-exact."""
+    P, H, W = _planes(x, 'flip')
+    out = torch.empty_like(x)
+    check(lib().ss_flip(x.element_size(), _p(x), _p(out), P, H, W, 1 if horizontal else 0, _stream()))
+    return out
+
+
+def warp_nearest(x, coef, kind, fill_bits=()):
+    """x [..., H, W]; coef float32 [n, 8] on the device (n divides the plane count: plane p uses row p // (planes / n));
+    kind 0 affine (inverse matrix m0..m5), 1 perspective (8 coefficients); fill_bits: up to 16 integer bit patterns, plane p takes
+    fill_bits[p % len] where its source falls outside the image."""
+    import ctypes
+    P, H, W = _planes(x, 'warp_nearest')
+    if coef.dtype != torch.float32 or coef.dim() != 2 or coef.shape[1] != 8 or not coef.is_contiguous() or coef.device != x.device:
+        raise ValueError('warp_nearest: coef must be a contiguous float32 [n, 8] tensor on the device of x')
+    n = coef.shape[0]
+    if n == 0 or P % n:
+        raise ValueError('warp_nearest: the transform count must divide the plane count')
+    if len(fill_bits) > 16:
+        raise ValueError('warp_nearest: at most 16 fill patterns')
+    arr = (ctypes.c_uint64 * max(1, len(fill_bits)))(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in fill_bits])
+    out = torch.empty_like(x)
+    check(lib().ss_warp_nearest(kind, x.element_size(), _p(x), _p(out), P, H, W, _p(coef), n, arr, len(fill_bits), _stream()))
+    return out
+
+
 def stage_label(src):
     """uint8 labels (any shape) -> int64."""
     dev = _dev(src)
