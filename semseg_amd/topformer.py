@@ -307,14 +307,27 @@ class TopFormerBackBone(nn.Module):
             out[name] = (ops.inject_fuse(local, ga, ge, B, ph, pw, hg, wg), ph, pw)
         return out
 
+    @staticmethod
+    def _fingerprint(model):
+        """(sum of tensor versions, sum of storage addresses) over every parameter and buffer the folded plan was built from: moves
+        with .to() / .float() / load_state_dict (new storage) and with any in-place edit (version counter), ~30 us per forward."""
+        root = model if isinstance(model, nn.Module) else model.backbone
+        ver = ptr = 0
+        for t in list(root.parameters()) + list(root.buffers()):
+            ver += t._version
+            ptr += t.data_ptr()
+        return ver, ptr
+
     def _plan_for(self, model, x):
         if self.training:
             raise NotImplementedError('TopFormer on the MI355X path is inference-only (call .eval()); training-mode BatchNorm is not built yet')
-        key = (compute_dtype_for(x), model.head is not None)
-        if key not in self._plans:
+        key = (compute_dtype_for(x), model.head is not None, x.device)
+        fp = self._fingerprint(model)
+        hit = self._plans.get(key)
+        if hit is None or hit[0] != fp:
             with torch.no_grad():
-                self._plans[key] = _Plan(model, key[0])
-        return self._plans[key]
+                hit = self._plans[key] = (fp, _Plan(model, key[0]))
+        return hit[1]
 
     def forward(self, x: Tensor):
         holder = _BackboneOnly(self)
