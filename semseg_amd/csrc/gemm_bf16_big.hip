@@ -258,7 +258,10 @@ static int cu_count() {
 
 bool ss_big_nt_ok(const FastGemm& p) {
     // MFMA-bound shapes only: enough k-tiles to amortise the tile's fill and drain, whole 256-column tiles, a full chip
-    if (p.K % 64 || p.K < 256 || p.N % 256) return false;
+    if (p.K % 64 || p.K < 128 || p.N % 256) return false;
+    // K = 128 (two k-tiles) only in the persistent form, where the next tile's fill overlaps the drain: 262144 x 512 x 128 runs in
+    // 84 us there against 105 us on the 128-tile kernel (half the bytes through L1 per flop); with N = 256 or K = 64 it does not pay
+    if (p.K < 256 && !(cdiv(p.M, 256) * (p.N / 256) >= 4 * cu_count() && p.N >= 512)) return false;
     return cdiv(p.M, 256) * (p.N / 256) >= 256;
 }
 
