@@ -439,6 +439,30 @@ def test_dwconvk_stride1_tiled_and_fallback(ops, dtype, k, C, H, W, pt, pl, act)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('k,C,H,W,act', [(3, 64, 64, 128, 2), (5, 96, 38, 150, 2), (3, 192, 18, 70, 3), (5, 32, 9, 64, 0), (3, 40, 20, 66, 2), (5, 64, 10, 40, 2)])
+def test_dwconvk_stride2_tiled_and_fallback(ops, dtype, k, C, H, W, act):
+    """depthwise k x k, stride 2 with the asymmetric AutoPadding of modules/layers.py:146-164 (TopFormer's down-sampling blocks), odd
+    sizes, with and without the fused residual, against F.conv2d on the explicitly padded input.  (An LDS-tiled stride-2 variant
+    passed this test and was slower than the per-pixel kernel: 1.09 vs 0.85 ms per TopFormer-B step; not kept.)"""
+    B = 2
+    x, w, b = rnd(B, C, H, W), rnd(C, 1, k, k, seed=1) / k, rnd(C, seed=2)
+    Ho, Wo = -(-H // 2), -(-W // 2)
+    ph, pw = max((Ho - 1) * 2 + k - H, 0), max((Wo - 1) * 2 + k - W, 0)
+    pt, pl = ph // 2, pw // 2
+    xp = F.pad(q(x, dtype), (pl, pw - pl, pt, ph - pt))
+    ref = F.conv2d(xp, w, b, stride=2, groups=C)
+    ref = {0: ref, 2: F.relu(ref), 3: F.relu6(ref)}[act]
+    assert ref.shape[-2:] == (Ho, Wo)
+    xn = dev(x.permute(0, 2, 3, 1).reshape(-1, C).contiguous(), dtype)
+    wt = dev(w.reshape(C, k * k).t().contiguous())
+    y = ops.dwconvk_fwd(xn, wt, dev(b), B, H, W, k, 2, pt, pl, Ho, Wo, act=act)
+    assert rel(y.view(B, Ho, Wo, C), ref.permute(0, 2, 3, 1)) < _tol(dtype)
+    res = rnd(B * Ho * Wo, C, seed=3)
+    y2 = ops.dwconvk_fwd(xn, wt, dev(b), B, H, W, k, 2, pt, pl, Ho, Wo, act=act, res=dev(res, dtype))
+    assert rel(y2.view(B, Ho, Wo, C), ref.permute(0, 2, 3, 1) + q(res, dtype).view(B, Ho, Wo, C)) < _tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('k,C,H,W', [(7, 96, 19, 70), (5, 32, 9, 130), (3, 64, 8, 64), (7, 8, 5, 3), (7, 40, 33, 20)])
 def test_dwconvk_weight_gradient(ops, dtype, k, C, H, W):
     """dW, db of a depthwise k x k (stride 1, padding k//2) against torch autograd; strips of several tiles, ragged edges; bitwise
