@@ -8,7 +8,7 @@ SegmentationMetrics.update (confusion matrix, as core/igniter.py:104 does every 
 bucketed gradient all-reduce (RCCL, N > 1) -> AdaBound step.  Inputs are synthetic UAVPal-shaped tiles resident in HBM.
 Rank 0 prints ONE JSON line; `roofline` describes the kernel family that dominates the step, measured live with HIP events
 on the launch stream in one extra instrumented step; `cpu_baseline` times the CPU oracle (port of the reference path) on
-one image of the same workload (same model, tile size and loss, fp32) on the host cores (N = 1 only).
+two images of the same workload (same model, tile size and loss, fp32) on the host cores (N = 1 only).
 """
 import argparse
 import json
@@ -278,7 +278,7 @@ def roofline_from_table(tab, traffic_ok=False):
 # ---------------------------------------------------------------- CPU baseline: the oracle (port of the reference path) on configs[0]
 def cpu_baseline():
     """The oracle (CPU restatement) on a bounded sample of the headline workload: the same model (MiT-B2 + Lawin 512), tile size
-    (1024 x 1024), loss and fwd + bwd, one image of the batch instead of 16, fp32, one step."""
+    (1024 x 1024), loss and fwd + bwd, two images of the batch instead of 16 (the head's image-pool BatchNorm needs two in training mode), fp32, two steps."""
     from oracle import lawin as olawin, losses as olosses
     from semseg_amd.detinit import det_state_dict
     from semseg_amd import shapes
@@ -290,16 +290,22 @@ def cpu_baseline():
         for k, v in sd.items():
             if v.is_floating_point() and 'running' not in k:
                 v.requires_grad_(True)
-    x, lab = synthetic_batch(1, 1024, 0, 'cpu')
+    x, lab = synthetic_batch(2, 1024, 0, 'cpu')
     crit = olosses.OhemCE(0, 0.7, 0.1)
-    t0 = time.time()
-    out = olawin.segmentor(sd_e, sd_h, x, 'B2', training=True)
-    loss = crit(out, lab)
-    loss.backward()
-    t = time.time() - t0
-    return {'value': 1.0 / t, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': 'the headline workload (MiT-B2 + Lawin(512, 6 cls), 1024x1024, fwd + OHEM-CE + bwd) on 1 image of the batch instead of 16, '
-                      'fp32, one step, no warm-up (%.1f s)' % t}
+    times = []
+    for _ in range(2):
+        t0 = time.time()
+        out = olawin.segmentor(sd_e, sd_h, x, 'B2', training=True)
+        loss = crit(out, lab)
+        loss.backward()
+        for sd in (sd_e, sd_h):
+            for v in sd.values():
+                v.grad = None
+        times.append(time.time() - t0)
+    t = min(times)
+    return {'value': 2.0 / t, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': 'the headline workload (MiT-B2 + Lawin(512, 6 cls), 1024x1024, fwd + OHEM-CE + bwd) on 2 images of the batch instead of 16, '
+                      'fp32, faster of two steps (%.1f s, %.1f s)' % tuple(times)}
 
 
 def topformer_inference(a, world, rank, dev):
