@@ -64,8 +64,16 @@ def _sz(dtype_code):
     return 4 if dtype_code == 0 else 2
 
 
+def _conv_patch_dims(name, a):
+    B, H, W, C, s, N = {'ss_conv_patch_fwd': a[2:7] + (a[12],), 'ss_conv_patch_dgrad': a[6:12], 'ss_conv_patch_wgrad': a[4:10]}[name]
+    return B * (H // s) * (W // s), N, s * s * C           # patches, output channels, patch length
+
+
 def entry_work(name, a):
     """-> (bound, algorithmic flops or bytes) for one launch, from its argument list (include/semseg_hip.h order)."""
+    if name.startswith('ss_conv_patch_'):
+        M, N, K = _conv_patch_dims(name, a)
+        return 'mfma', 2.0 * M * N * K
     if name == 'ss_gemm_nt':
         return 'mfma', 2.0 * a[8] * a[9] * a[10]
     if name in ('ss_gemm_tn', 'ss_gemm_tn_colsum'):
@@ -141,6 +149,9 @@ def entry_bytes(name, a):
     if name in ('ss_gemm_tn', 'ss_gemm_tn_colsum'):
         M, N, K = a[7:10]
         return (K * M + K * N) * _sz(a[0]) + M * N * 4
+    if name.startswith('ss_conv_patch_'):
+        M, N, K = _conv_patch_dims(name, a)
+        return (M * K + M * N) * _sz(a[0]) + N * K * (4 if name.endswith('wgrad') else _sz(a[0]))
     if name == 'ss_mit_attn_fwd':
         B, N, Nk, h, D = a[5:10]
         return (2.0 * B * N * h * D + 2.0 * B * Nk * h * D) * _sz(a[0])            # q, out; k, v
@@ -204,7 +215,7 @@ def shape_table(trace):
               f"{fl / per / 1e9:7.1f} TFLOP/s {byt / per / 1e6:7.0f} GB/s", file=sys.stderr)
 
 
-FAMILIES = (('gemm', ('ss_gemm',)), ('mit_attention', ('ss_mit_attn',)), ('depthwise_conv', ('ss_dwconv',)), ('batchnorm', ('ss_bn_',)),
+FAMILIES = (('gemm', ('ss_gemm', 'ss_conv_patch')), ('mit_attention', ('ss_mit_attn',)), ('depthwise_conv', ('ss_dwconv',)), ('batchnorm', ('ss_bn_',)),
             ('layernorm', ('ss_layernorm',)), ('lawin_window_attention', ('ss_lawin',)), ('resample', ('ss_bilinear', 'ss_im2col', 'ss_col2im')),
             ('loss_metrics', ('ss_ohem', 'ss_dice', 'ss_confusion', 'ss_label_hist')), ('optimizer', ('ss_adabound',)))
 
@@ -234,7 +245,7 @@ def roofline_from_table(tab, traffic_ok=False):
     fam = family_table(tab)
     total = sum(t['ms'] for t in tab.values())
     name, f = max(fam.items(), key=lambda kv: kv[1]['ms'])
-    out = {'kernel': 'gemm_kernel (ss_gemm_nt + ss_gemm_tn)' if name == 'gemm' else name, 'bound': f['bound'],
+    out = {'kernel': 'gemm_kernel (ss_gemm_nt + ss_gemm_tn + ss_conv_patch_*)' if name == 'gemm' else name, 'bound': f['bound'],
            'launches_per_step': f['calls'], 'avg_launch_us': 1e3 * f['ms'] / f['calls'], 'step_share': f['ms'] / total}
     if f['known_ms'] > 0:
         per_s = f['work'] / (f['known_ms'] * 1e-3)

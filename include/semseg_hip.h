@@ -141,6 +141,23 @@ int ss_mit_attn_bwd(int dtype, const void* q, const void* kv, const void* o, con
 int ss_im2col(int dtype, const void* x, void* col, int B, int H, int W, int C, int k, int s, int pad, int Kp, hipStream_t stream);
 int ss_col2im(int dtype, const void* col, void* dx, int B, int H, int W, int C, int k, int s, int pad, hipStream_t stream);
 
+/* ---- nn.Conv2d(C, N, kernel_size=s, stride=s) on a channels-last image [B, H, W, C] WITHOUT the patch matrix: the spatial-reduction
+ * conv of the MiT attention (modules/segformer.py:27-29 `sr`, sr = 8/4/2) and ConvNeXt's 2x2 down-sampling (modules/convnext.py:96-104).
+ * The tile GEMM reads / writes the image itself (a patch row is s runs of s*C contiguous elements, W*C apart), so ss_im2col / ss_col2im
+ * and their [M, s*s*C] matrix never exist.  M = B*(H/s)*(W/s) patches, weight columns in (ky, kx, c) order as ss_im2col's.
+ * ss_conv_patch_ok: 1 when the three entry points take the shape (bf16, H % s == 0, W % s == 0, (s*C) % 64 == 0, C % 8 == 0,
+ * N % 8 == 0), else 0 -- callers then use ss_im2col + ss_gemm_*.
+ * fwd: y [M, N] = patches(x) . w [N, s*s*C]^T + bias.   dgrad: dx [B, H, W, C] = dy [M, N] . wt [s*s*C, N]^T, every pixel written once.
+ * wgrad: dw [N, s*s*C] fp32 = dy^T . patches(x), dbias [N] = column sums of dy (or null); workspace as ss_gemm_tn's. */
+int ss_conv_patch_ok(int dtype, int B, int H, int W, int C, int s, int N);
+int ss_conv_patch_fwd(int dtype, const void* x, int B, int H, int W, int C, int s, const void* w, int64_t ldw, const float* bias,
+                      void* y, int64_t ldy, int N, hipStream_t stream);
+int ss_conv_patch_dgrad(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldw, void* dx, int B, int H, int W, int C,
+                        int s, int N, hipStream_t stream);
+int64_t ss_conv_patch_wgrad_workspace(int dtype, int B, int H, int W, int C, int s, int N);
+int ss_conv_patch_wgrad(int dtype, const void* dy, int64_t lddy, const void* x, int B, int H, int W, int C, int s, int N, float* dw,
+                        int64_t lddw, float* dbias, void* workspace, int64_t ws_bytes, hipStream_t stream);
+
 /* ---- F.interpolate(mode='bilinear', align_corners=False) (modules/lawin.py:194-196,205-208,213-218; the S/4 -> S logits
  * resize of SURVEY.md §0.2), reading/writing channel slices (ldx/ldy) of concat buffers. */
 int ss_bilinear_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,

@@ -48,7 +48,7 @@ class _Traced:
 
     def __getattr__(self, name):
         fn = getattr(self._h, name)
-        if name.endswith('_workspace') or name in ('ss_last_error', 'ss_version'):
+        if name.endswith(('_workspace', '_ok')) or name in ('ss_last_error', 'ss_version'):     # host-only queries launch nothing
             return fn
         import torch
 

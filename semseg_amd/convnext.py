@@ -44,25 +44,31 @@ class _LNFn(_ParamFn):
 
 
 class _PatchConvFn(_ParamFn):
-    """nn.Conv2d(c1, c2, k, s) with k == s and no padding (stem 4x4/s4, down-sampling 2x2/s2) as im2col + GEMM."""
+    """nn.Conv2d(c1, c2, k, s) with k == s and no padding (stem 4x4/s4, down-sampling 2x2/s2): a GEMM over the image's own patches
+    where the tile kernels can address them (ss_conv_patch_*: the down-sampling layers), else im2col + GEMM (the 3-channel stem)."""
 
     @staticmethod
     def fwd(P, x, meta):
         B, H, W, Cin, k = meta
-        col, ho, wo = ops.im2col(x, B, H, W, Cin, k, k, 0)
         wp = weightprep.pack(P['weight'], x.dtype)
+        if ops.conv_patch_ok(x, B, H, W, Cin, k, wp.shape[0]):
+            return ops.conv_patch_fwd(x, B, H, W, Cin, k, wp, bias=P['bias']), {'x': x}
+        col, ho, wo = ops.im2col(x, B, H, W, Cin, k, k, 0)
         return ops.gemm_nt(col, wp, bias=P['bias']), {'col': col}
 
     @staticmethod
     def bwd(P, S, dy, meta):
         B, H, W, Cin, k = meta
-        gp, db = ops.gemm_tn(dy, S['col'], colsum=True)
-        G = {'bias': db, 'weight': ops.unpack_conv_wgrad(gp, dy.shape[1], Cin, k)}
-        dx = None
-        if Cin % 8 == 0:                                     # the RGB image needs no gradient
-            wpt = weightprep.pack(P['weight'], dy.dtype, transposed=True)
-            dx = ops.col2im(ops.gemm_nt(dy, wpt), B, H, W, Cin, k, k, 0)
-        return dx, G
+        wpt = weightprep.pack(P['weight'], dy.dtype, transposed=True) if Cin % 8 == 0 else None
+        if 'x' in S:
+            gp, db = ops.conv_patch_wgrad(dy, S['x'], B, H, W, Cin, k)
+            dx = ops.conv_patch_dgrad(dy, wpt, B, H, W, Cin, k)
+        else:
+            gp, db = ops.gemm_tn(dy, S['col'], colsum=True)
+            dx = None                                            # the RGB image needs no gradient
+            if wpt is not None:
+                dx = ops.col2im(ops.gemm_nt(dy, wpt), B, H, W, Cin, k, k, 0)
+        return dx, {'bias': db, 'weight': ops.unpack_conv_wgrad(gp, dy.shape[1], Cin, k)}
 
 
 class _BlockFn(_ParamFn):

@@ -355,8 +355,8 @@ static int tn_big_enabled() {
 }
 
 // returns true when the split was planned for the 256-tile bf16 kernel (gemm_bf16_tn_big.hip)
-static bool tn_plan(int64_t M, int64_t N, int64_t R, int bk, int* nsplit, int64_t* rps) {
-    if (bk == 64 && tn_big_enabled() && ss_big_tn_plan(M, N, R, nsplit, rps)) return true;
+static bool tn_plan(int64_t M, int64_t N, int64_t R, int bk, int* nsplit, int64_t* rps, bool allow_big = true) {
+    if (allow_big && bk == 64 && tn_big_enabled() && ss_big_tn_plan(M, N, R, nsplit, rps)) return true;
     // split the reduction rows so that ~8 workgroups per CU exist (tail quantisation), every split has >= 4 k-tiles, and the fp32 slabs
     // (written once, read once) stay below ~a quarter of the operand bytes
     int64_t tiles = cdiv(M, 128) * cdiv(N, N <= 64 ? 64 : 128);
@@ -386,7 +386,7 @@ extern "C" int64_t ss_gemm_tn_workspace(int dtype, int64_t M, int64_t N, int64_t
 
 static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
                         int64_t R, void* workspace, int64_t ws_bytes, int accumulate, float* colsum, int colsum_accumulate,
-                        hipStream_t stream);
+                        hipStream_t stream, const PatchMap* pm = nullptr);
 
 extern "C" int ss_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                           int64_t M, int64_t N, int64_t R, void* workspace, int64_t ws_bytes, int accumulate, hipStream_t stream) {
@@ -402,13 +402,13 @@ extern "C" int ss_gemm_tn_colsum(int dtype, const void* A, int64_t lda, const vo
 
 static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
                         int64_t R, void* workspace, int64_t ws_bytes, int accumulate, float* colsum, int colsum_accumulate,
-                        hipStream_t stream) {
+                        hipStream_t stream, const PatchMap* pm) {
     SS_CHECK(A && B && C && workspace, "ss_gemm_tn: null operand");
     SS_CHECK(M > 0 && N > 0 && R > 0 && N < (1 << 30) && M < (1 << 30), "ss_gemm_tn: bad shape");
-    SS_CHECK(lda >= M && ldb >= N && ldc >= N, "ss_gemm_tn: leading dimension smaller than the row");
+    SS_CHECK(lda >= M && (pm || ldb >= N) && ldc >= N, "ss_gemm_tn: leading dimension smaller than the row");
     int ns; int64_t rps;
     int bk = dtype == SS_BF16 ? 64 : 32;
-    const bool big = tn_plan(M, N, R, bk, &ns, &rps);
+    const bool big = tn_plan(M, N, R, bk, &ns, &rps, !pm);
     const int64_t ws_need = ((int64_t)ns * M * N + kColsumWsRows * M) * 4;
     SS_CHECK(ws_bytes >= ws_need, "ss_gemm_tn: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)ws_need);
     float* cs_ws = (float*)workspace + (int64_t)ns * M * N;
@@ -420,7 +420,15 @@ static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, in
     p.vecA = aligned16(A) && lda % vec == 0 && M % vec == 0;
     p.vecB = aligned16(B) && ldb % vec == 0 && N % vec == 0;
     dim3 block(256);
-    if (dtype == SS_BF16 && ss_skinny_tn_ok(B, ldb, M, N)) {
+    if (pm) {                                              // B is addressed as image patches: the 128-row tile kernel only
+        SS_CHECK(dtype == SS_BF16 && ss_fast_tn_ok(A, lda, B, ldb, M, N), "ss_conv_patch_wgrad: operands must be bf16, 16-byte aligned, multiples of 8");
+        FastGemm f{};
+        f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = workspace; f.M = M; f.N = (int)N; f.K = R; f.lda = lda; f.ldb = ldb; f.ldc = N;
+        f.k_per_split = rps; f.pm = *pm;
+        if (colsum && ns <= kColsumWsRows) { f.colsum_ws = cs_ws; cs_fused = true; }
+        int rc = ss_patch_tn_launch(f, ns, stream);
+        if (rc) return rc;
+    } else if (dtype == SS_BF16 && ss_skinny_tn_ok(B, ldb, M, N)) {
         FastGemm f{};
         f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = workspace; f.M = M; f.N = (int)N; f.K = R; f.lda = lda; f.ldb = ldb; f.ldc = N;
         f.k_per_split = rps;
@@ -490,4 +498,64 @@ static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, in
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rb), dim3(256), 0, stream, (const float*)workspace, ns, M, (int)N, C, ldc, accumulate);
     SS_LAUNCH_CHECK();
     return 0;
+}
+
+// ------------------------------------------------------------------ convolutions with kernel = stride, without the patch matrix
+// nn.Conv2d(C, N, s, s) on a channels-last image [B, H, W, C] (modules/segformer.py:27 `sr`, modules/convnext.py:96-104 down-sampling)
+// is a GEMM whose patch operand is the image itself, read (or written) s runs of s*C elements per patch row (PatchMap).
+static bool patch_map(PatchMap* pm, int side, int B, int H, int W, int C, int s) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || s <= 0 || H % s || W % s || C % 8) return false;
+    const int64_t kc = (int64_t)s * C;
+    if (kc % 64 || (int64_t)B * H * W >= (1LL << 31)) return false;
+    pm->side = side; pm->kc = (int)kc; pm->cs = (int64_t)W * C; pm->outer = (int64_t)s * W * C; pm->inner = fast_div((unsigned)(W / s));
+    return true;
+}
+
+extern "C" int ss_conv_patch_ok(int dtype, int B, int H, int W, int C, int s, int N) {
+    PatchMap pm;
+    return dtype == SS_BF16 && N > 0 && N % 8 == 0 && patch_map(&pm, 1, B, H, W, C, s);
+}
+
+extern "C" int ss_conv_patch_fwd(int dtype, const void* x, int B, int H, int W, int C, int s, const void* w, int64_t ldw, const float* bias,
+                                 void* y, int64_t ldy, int N, hipStream_t stream) {
+    FastGemm f{};
+    SS_CHECK(x && w && y && ss_conv_patch_ok(dtype, B, H, W, C, s, N), "ss_conv_patch_fwd: needs bf16, H and W multiples of s, s*C a multiple of 64, N of 8");
+    const int64_t K = (int64_t)s * s * C, M = (int64_t)B * (H / s) * (W / s);
+    SS_CHECK(ldw >= K && ldy >= N && ss_fast_nt_ok(x, s * C, w, ldw, y, ldy, M, N, K, nullptr, 0, bias), "ss_conv_patch_fwd: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+    patch_map(&f.pm, 1, B, H, W, C, s);
+    f.A = (const bf16*)x; f.B = (const bf16*)w; f.C = y; f.M = M; f.N = N; f.K = K; f.lda = (int64_t)s * C; f.ldb = ldw; f.ldc = ldy;
+    f.bias = bias; f.rows_per_scale = 1; f.k_per_split = K;
+    return ss_patch_nt_launch(f, stream);
+}
+
+// dx [B, H, W, C] = the patches dy [M, N] . wt [s*s*C, N]^T, each written to its place in the image (every pixel belongs to one patch)
+extern "C" int ss_conv_patch_dgrad(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldw, void* dx, int B, int H, int W, int C,
+                                   int s, int N, hipStream_t stream) {
+    FastGemm f{};
+    SS_CHECK(dy && wt && dx && ss_conv_patch_ok(dtype, B, H, W, C, s, N), "ss_conv_patch_dgrad: needs bf16, H and W multiples of s, s*C a multiple of 64, N of 8");
+    const int64_t K = (int64_t)s * s * C, M = (int64_t)B * (H / s) * (W / s);
+    SS_CHECK(ldw >= N && lddy >= N && ss_fast_nt_ok(dy, lddy, wt, ldw, dx, s * C, M, K, N, nullptr, 0, nullptr), "ss_conv_patch_dgrad: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+    patch_map(&f.pm, 2, B, H, W, C, s);
+    f.A = (const bf16*)dy; f.B = (const bf16*)wt; f.C = dx; f.M = M; f.N = (int)K; f.K = N; f.lda = lddy; f.ldb = ldw; f.ldc = (int64_t)s * C;
+    f.rows_per_scale = 1; f.k_per_split = N;
+    return ss_patch_nt_launch(f, stream);
+}
+
+extern "C" int64_t ss_conv_patch_wgrad_workspace(int dtype, int B, int H, int W, int C, int s, int N) {
+    if (s <= 0) return 0;
+    int ns; int64_t rps;
+    const int64_t K = (int64_t)s * s * C, M = (int64_t)B * (H / s) * (W / s);
+    tn_plan(N, K, M, 64, &ns, &rps, false);
+    return ((int64_t)ns * N * K + kColsumWsRows * N) * (int64_t)sizeof(float);
+}
+
+// dw [N, s*s*C] fp32 = dy [M, N]^T . patches(x), dbias [N] = column sums of dy (or null)
+extern "C" int ss_conv_patch_wgrad(int dtype, const void* dy, int64_t lddy, const void* x, int B, int H, int W, int C, int s, int N, float* dw,
+                                   int64_t lddw, float* dbias, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+    PatchMap pm;
+    SS_CHECK(dy && x && dw && ss_conv_patch_ok(dtype, B, H, W, C, s, N), "ss_conv_patch_wgrad: needs bf16, H and W multiples of s, s*C a multiple of 64, N of 8");
+    patch_map(&pm, 4, B, H, W, C, s);
+    const int64_t K = (int64_t)s * s * C, M = (int64_t)B * (H / s) * (W / s);
+    SS_CHECK(lddy % 8 == 0, "ss_conv_patch_wgrad: lddy must be a multiple of 8");
+    return gemm_tn_impl(dtype, dy, lddy, x, (int64_t)s * C, dw, lddw, N, K, M, workspace, ws_bytes, 0, dbias, 0, stream, &pm);
 }

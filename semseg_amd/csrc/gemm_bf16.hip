@@ -29,7 +29,7 @@ __device__ __forceinline__ int nt_slot(int row, int chunk) {      // 16-byte slo
     return R * 16 + ((((row & 1) << 3) | chunk) ^ (R & 15));
 }
 
-template <int BN>
+template <int BN, bool PATCH = false>
 __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(FastGemm p) {
     constexpr int BM = 128, BK = 64;
     constexpr int NB = BN / 32;                       // 16-byte chunks of B per thread per k-tile
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(FastGemm p) {
     for (int i = 0; i < 4; ++i) {
         int64_t r = m0 + srow + i * 32;
         oka[i] = r < p.M;
-        pa[i] = p.A + (oka[i] ? r : 0) * p.lda + sch * 8;
+        if (!oka[i]) r = 0;
+        pa[i] = p.A + (PATCH && (p.pm.side & 1) ? patch_row(p.pm, r, p.lda) : r * p.lda) + sch * 8;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -68,8 +69,9 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(FastGemm p) {
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     auto gload = [&](int k0) {
         const bool kin = k0 + sch * 8 < K;
+        const int64_t ka = PATCH && (p.pm.side & 1) ? patch_col(p.pm, k0) : k0;      // a k-tile lies inside one run (kc % 64 == 0)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = (oka[i] && kin) ? *(const bf16x8*)(pa[i] + k0) : zero;
+        for (int i = 0; i < 4; ++i) ra[i] = (oka[i] && kin) ? *(const bf16x8*)(pa[i] + ka) : zero;
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = (okb[i] && kin) ? *(const bf16x8*)(pb[i] + k0) : zero;
     };
@@ -131,12 +133,16 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(FastGemm p) {
 #pragma unroll
     for (int ps = 0; ps < BM / RPP; ++ps) {
         int row = ps * RPP + erow;
-        if (m0 + row < p.M && ncol_ok) nt_store_chunk(p, C, m0 + row, n0 + ech * 8, *(const bf16x8*)(smem + row * EP + ech * 16));
+        if (m0 + row < p.M && ncol_ok) {
+            if (PATCH && (p.pm.side & 2))
+                *(bf16x8*)(C + patch_row(p.pm, m0 + row, p.ldc) + patch_col(p.pm, n0 + ech * 8)) = *(const bf16x8*)(smem + row * EP + ech * 16);
+            else nt_store_chunk(p, C, m0 + row, n0 + ech * 8, *(const bf16x8*)(smem + row * EP + ech * 16));
+        }
     }
 }
 
 // ------------------------------------------------------------------ TN (weight gradient)
-template <int BN>
+template <int BN, bool PATCH = false>
 __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(FastGemm p) {
     constexpr int BM = 128, BK = 64;
     constexpr int PA = BM * 2 + 64, PB = BN * 2 + 64;   // row pitches in bytes
@@ -160,14 +166,15 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(FastGemm p) {
     const int arow = tid / CA, ach = tid % CA, brow = tid / CB, bch = tid % CB;
     const bool oka = m0 + ach * 8 < p.M, okb = n0 + bch * 8 < p.N;
     const bf16* pa = p.A + m0 + ach * 8;
-    const bf16* pb = p.B + n0 + bch * 8;
+    const bf16* pb = p.B + (PATCH ? (okb ? patch_col(p.pm, n0 + bch * 8) : 0) : n0 + bch * 8);     // a column tile lies inside one run (kc % BN == 0)
     bf16x8 ra[NA], rb[NBk];
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     auto gload = [&](int64_t r0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) { int64_t r = r0 + arow + i * (256 / CA); ra[i] = (oka && r < kend) ? *(const bf16x8*)(pa + r * p.lda) : zero; }
 #pragma unroll
-        for (int i = 0; i < NBk; ++i) { int64_t r = r0 + brow + i * (256 / CB); rb[i] = (okb && r < kend) ? *(const bf16x8*)(pb + r * p.ldb) : zero; }
+        for (int i = 0; i < NBk; ++i) { int64_t r = r0 + brow + i * (256 / CB); const bool in = okb && r < kend;
+            rb[i] = in ? *(const bf16x8*)(pb + (PATCH ? patch_row(p.pm, r, p.ldb) : r * p.ldb)) : zero; }
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -299,6 +306,34 @@ int ss_fast_tn_launch(FastGemm p, int nsplit, hipStream_t st) {
         p.ntn = (int)cdiv(p.N, 128);
         p.ntiles = (int)(p.ntn * cdiv(p.M, 128));
         hipLaunchKernelGGL(gemm_tn_bf16_kernel<128>, dim3((unsigned)(p.ntiles * nsplit)), dim3(256), 0, st, p);
+    }
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same tile kernels with one operand addressed as image patches (PatchMap): the convolutions with kernel = stride.
+int ss_patch_nt_launch(FastGemm p, hipStream_t st) {
+    const bool narrow = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 1024);
+    if (narrow) {
+        p.ntn = (int)cdiv(p.N, 64);
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<64, true>), dim3((unsigned)(p.ntn * cdiv(p.M, 128))), dim3(256), 0, st, p);
+    } else {
+        p.ntn = (int)cdiv(p.N, 128);
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, true>), dim3((unsigned)(p.ntn * cdiv(p.M, 128))), dim3(256), 0, st, p);
+    }
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+int ss_patch_tn_launch(FastGemm p, int nsplit, hipStream_t st) {
+    if (p.pm.kc % 128) {
+        p.ntn = (int)cdiv(p.N, 64);
+        p.ntiles = (int)(p.ntn * cdiv(p.M, 128));
+        hipLaunchKernelGGL((gemm_tn_bf16_kernel<64, true>), dim3((unsigned)(p.ntiles * nsplit)), dim3(256), 0, st, p);
+    } else {
+        p.ntn = (int)cdiv(p.N, 128);
+        p.ntiles = (int)(p.ntn * cdiv(p.M, 128));
+        hipLaunchKernelGGL((gemm_tn_bf16_kernel<128, true>), dim3((unsigned)(p.ntiles * nsplit)), dim3(256), 0, st, p);
     }
     SS_LAUNCH_CHECK();
     return 0;

@@ -2,6 +2,22 @@
 #pragma once
 #include "common.h"
 
+// One operand of a GEMM addressed as the non-overlapping s x s patches of a channels-last image [B, H, W, C] (a convolution with
+// kernel = stride = s needs no patch matrix: a patch row is s runs of s*C contiguous elements, W*C apart).  Logical row r (patch
+// (b*Ho + ho)*Wo + wo) starts at (r / inner) * outer + (r % inner) * ld, logical column k = (ky*s + kx)*C + c sits (k / kc) * cs + k % kc
+// further on: inner = Wo, outer = s*W*C, ld = kc = s*C, cs = W*C.  Tiles never straddle a run: kc % 64 == 0 (k-tiles of the NT A
+// operand), kc % BN == 0 (column tiles of the TN B operand), kc % 8 == 0 (16-byte chunks of the NT output).
+struct PatchMap {
+    int side;                               // 0 none; 1 the NT A operand; 2 the NT output; 4 the TN B operand
+    int kc; int64_t cs, outer;
+    FastDiv inner;
+};
+__device__ __forceinline__ int64_t patch_row(const PatchMap& pm, int64_t r, int64_t ld) {
+    const unsigned q = fdiv((unsigned)r, pm.inner);
+    return q * pm.outer + (int64_t)((unsigned)r - q * pm.inner.d) * ld;
+}
+__device__ __forceinline__ int64_t patch_col(const PatchMap& pm, int k) { const int q = k / pm.kc; return q * pm.cs + (k - q * pm.kc); }
+
 struct FastGemm {
     const bf16* A; const bf16* B; void* C;
     int64_t M; int N; int64_t K;
@@ -13,6 +29,7 @@ struct FastGemm {
     int dbg;
     float* colsum_ws;                       // TN: per-split column sums of A, [nsplit][M] (or null)
     bf16* C2; int64_t ldc2;                 // NT: second output (or null): C2 gets the tile as the epilogue left it, C gets GELU of it
+    PatchMap pm;                            // patch-addressed operand (side = 0: none); only the 128-row tile kernels take it
 };
 
 // Copy-out of one 16-byte chunk of the NT kernels' LDS tile image: plain, or -- when C2 is set -- the pre-activation to C2 and
@@ -33,6 +50,8 @@ bool ss_fast_nt_ok(const void* A, int64_t lda, const void* B, int64_t ldb, const
 int ss_fast_nt_launch(FastGemm p, hipStream_t st);
 bool ss_fast_tn_ok(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N);
 int ss_fast_tn_launch(FastGemm p, int nsplit, hipStream_t st);
+int ss_patch_nt_launch(FastGemm p, hipStream_t st);
+int ss_patch_tn_launch(FastGemm p, int nsplit, hipStream_t st);
 bool ss_skinny_nt_ok(const FastGemm& p);
 int ss_skinny_nt_launch(const FastGemm& p, hipStream_t st);
 bool ss_skinny_tn_ok(const void* B, int64_t ldb, int64_t M, int64_t N);

@@ -337,6 +337,50 @@ def col2im(col, B, H, W, C, k, s, pad):
     return dx
 
 
+def conv_patch_ok(x, B, H, W, C, s, N):
+    """True when conv(kernel = stride = s) on x [B*H*W, C] runs without the patch matrix (ss_conv_patch_*)."""
+    return bool(x.is_cuda and x.is_contiguous() and x.numel() == B * H * W * C and lib().ss_conv_patch_ok(dt(x), B, H, W, C, s, N))
+
+
+def conv_patch_fwd(x, B, H, W, C, s, w, bias=None):
+    """x [B*H*W, C], w [N, s*s*C] (columns ky, kx, c) -> y [B*(H/s)*(W/s), N] = conv(x) + bias, no im2col matrix."""
+    dev = _dev(x)
+    N, K, ldw = _mat(w, 'w')
+    if K != s * s * C or w.dtype != x.dtype or not conv_patch_ok(x, B, H, W, C, s, N):
+        raise ValueError('conv_patch_fwd: shape outside the patch GEMM (see ss_conv_patch_ok)')
+    _f32(bias, 'bias', N)
+    y = torch.empty((B * (H // s) * (W // s), N), dtype=x.dtype, device=dev)
+    check(lib().ss_conv_patch_fwd(dt(x), _p(x), B, H, W, C, s, _p(w), ldw, _p(bias), _p(y), N, N, _stream()))
+    return y
+
+
+def conv_patch_dgrad(dy, wt, B, H, W, C, s):
+    """dy [M, N], wt [s*s*C, N] -> dx [B*H*W, C] (every pixel belongs to exactly one patch)."""
+    dev = _dev(dy)
+    M, N, lddy = _mat(dy, 'dy')
+    K, Nw, ldw = _mat(wt, 'wt')
+    if K != s * s * C or Nw != N or wt.dtype != dy.dtype or M != B * (H // s) * (W // s):
+        raise ValueError('conv_patch_dgrad: bad shapes')
+    dx = torch.empty((B * H * W, C), dtype=dy.dtype, device=dev)
+    if not conv_patch_ok(dx, B, H, W, C, s, N):
+        raise ValueError('conv_patch_dgrad: shape outside the patch GEMM (see ss_conv_patch_ok)')
+    check(lib().ss_conv_patch_dgrad(dt(dy), _p(dy), lddy, _p(wt), ldw, _p(dx), B, H, W, C, s, N, _stream()))
+    return dx
+
+
+def conv_patch_wgrad(dy, x, B, H, W, C, s, want_bias=True):
+    """-> (dw [N, s*s*C] fp32, dbias [N] fp32 or None)."""
+    dev = _dev(dy)
+    M, N, lddy = _mat(dy, 'dy')
+    if M != B * (H // s) * (W // s) or x.dtype != dy.dtype or not conv_patch_ok(x, B, H, W, C, s, N):
+        raise ValueError('conv_patch_wgrad: bad shapes')
+    dw = torch.empty((N, s * s * C), dtype=torch.float32, device=dev)
+    db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+    ws = workspace(dev, lib().ss_conv_patch_wgrad_workspace(dt(dy), B, H, W, C, s, N))
+    check(lib().ss_conv_patch_wgrad(dt(dy), _p(dy), lddy, _p(x), B, H, W, C, s, N, _p(dw), s * s * C, _p(db), _p(ws), ws.numel(), _stream()))
+    return dw, db
+
+
 def bilinear_fwd(x, B, hi, wi, ho, wo, out=None):
     """x [B*hi*wi, C] (row stride ld) -> out [B*ho*wo, C] (may be a channel slice of a wider buffer)."""
     dev = _dev(x)

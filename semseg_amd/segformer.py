@@ -48,11 +48,17 @@ def attn_forward(P, x, B, h, w, head, sr, res=None, keep=None):
     S = {'x': x}
     q = ops.gemm_nt(x, w_fwd(P['q.weight'], T), bias=P['q.bias'])
     if sr > 1:
-        col, ho, wo = ops.im2col(x, B, h, w, C, sr, sr, 0)
         wp = weightprep.pack(P['sr.weight'], T)
-        s = ops.gemm_nt(col, wp, bias=P['sr.bias'])
+        if ops.conv_patch_ok(x, B, h, w, C, sr, C):             # the GEMM reads the patches out of x itself: no patch matrix
+            s = ops.conv_patch_fwd(x, B, h, w, C, sr, wp, bias=P['sr.bias'])
+            ho, wo = h // sr, w // sr
+            S.update(col=None)
+        else:
+            col, ho, wo = ops.im2col(x, B, h, w, C, sr, sr, 0)
+            s = ops.gemm_nt(col, wp, bias=P['sr.bias'])
+            S.update(col=col)
         xr, m, r = ops.layernorm_fwd(s, P['norm.weight'], P['norm.bias'], 1e-5)
-        S.update(col=col, s=s, m=m, r=r)
+        S.update(s=s, m=m, r=r)
         Nk = ho * wo
     else:
         xr, Nk = x, N
@@ -77,10 +83,14 @@ def attn_backward(P, S, dout, B, h, w, head, sr):
     if sr > 1:
         ds, dgb = ops.layernorm_bwd(dxr, S['s'], S['m'], S['r'], P['norm.weight'])
         G['norm.weight'], G['norm.bias'] = dgb[0], dgb[1]
-        gp, G['sr.bias'] = ops.gemm_tn(ds, S['col'], colsum=True)
-        G['sr.weight'] = ops.unpack_conv_wgrad(gp, C, C, sr)
         wpt = weightprep.pack(P['sr.weight'], T, transposed=True)
-        dxa = ops.col2im(ops.gemm_nt(ds, wpt), B, h, w, C, sr, sr, 0)
+        if S['col'] is None:
+            gp, G['sr.bias'] = ops.conv_patch_wgrad(ds, S['x'], B, h, w, C, sr)
+            dxa = ops.conv_patch_dgrad(ds, wpt, B, h, w, C, sr)
+        else:
+            gp, G['sr.bias'] = ops.gemm_tn(ds, S['col'], colsum=True)
+            dxa = ops.col2im(ops.gemm_nt(ds, wpt), B, h, w, C, sr, sr, 0)
+        G['sr.weight'] = ops.unpack_conv_wgrad(gp, C, C, sr)
     else:
         dxa = dxr
     G['q.weight'], G['q.bias'] = linear_grads(dq, S['x'])

@@ -301,6 +301,47 @@ def test_im2col_conv(ops, dtype, C, k, s, pad):
         assert rel(dx.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _gtol(dtype)
 
 
+@pytest.mark.parametrize('B,H,W,C,s,O', [(2, 32, 24, 64, 8, 64), (3, 16, 40, 128, 4, 128), (2, 12, 20, 320, 2, 320), (1, 8, 8, 32, 2, 72),
+                                         (2, 64, 64, 96, 2, 192), (5, 24, 8, 16, 4, 8)])
+def test_conv_patch_gemms_without_patch_matrix(ops, B, H, W, C, s, O):
+    """conv(kernel = stride = s) with the GEMM reading / writing the image itself (modules/segformer.py:27-29 sr conv, ConvNeXt
+    down-sampling): forward, data gradient and weight / bias gradient against F.conv2d on the bf16-rounded operands (2e-2 budget, measured
+    ~3e-3), and bit for bit against the im2col -> GEMM -> col2im route, which adds the same products in the same order."""
+    dtype = torch.bfloat16
+    x, w, b = rnd(B, C, H, W), rnd(O, C, s, s, seed=1) / math.sqrt(C * s * s), rnd(O, seed=3)
+    xr, wr = q(x, dtype).requires_grad_(True), q(w, dtype).requires_grad_(True)
+    ref = F.conv2d(xr, wr, b, stride=s)
+    dy = rnd(*ref.shape, seed=2)
+    ref.backward(q(dy, dtype))
+    xn = ops.nchw_to_nhwc(dev(x), dtype)
+    assert ops.conv_patch_ok(xn, B, H, W, C, s, O)
+    wp, wpt = ops.pack_conv_weight(dev(w), dtype)
+    y = ops.conv_patch_fwd(xn, B, H, W, C, s, wp, bias=dev(b))
+    ho, wo = H // s, W // s
+    assert rel(y.view(B, ho, wo, O), ref.permute(0, 2, 3, 1)) < 2e-2
+    col, _, _ = ops.im2col(xn, B, H, W, C, s, s, 0)
+    assert torch.equal(y, ops.gemm_nt(col, wp, bias=dev(b)))
+    dyd = dev(dy.permute(0, 2, 3, 1).reshape(-1, O).contiguous(), dtype)
+    gp, gb = ops.conv_patch_wgrad(dyd, xn, B, H, W, C, s)
+    assert rel(ops.unpack_conv_wgrad(gp, O, C, s), wr.grad) < 1e-2
+    assert rel(gb, q(dy, dtype).sum((0, 2, 3))) < 1e-4
+    gp2, gb2 = ops.gemm_tn(dyd, col, colsum=True)
+    assert rel(gp, gp2) < 1e-5 and rel(gb, gb2) < 1e-6            # the split plans may differ (tile choice), the products do not
+    dx = ops.conv_patch_dgrad(dyd, wpt, B, H, W, C, s)
+    assert rel(dx.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < 2e-2
+    assert torch.equal(dx, ops.col2im(ops.gemm_nt(dyd, wpt), B, H, W, C, s, s, 0))
+
+
+def test_conv_patch_ok_rejects_what_the_patch_gemm_cannot_address(ops):
+    x = torch.zeros(2 * 32 * 32, 64, device='cuda', dtype=torch.bfloat16)
+    assert ops.conv_patch_ok(x, 2, 32, 32, 64, 8, 64)
+    assert not ops.conv_patch_ok(x.float(), 2, 32, 32, 64, 8, 64)                 # fp32 goes through im2col
+    assert not ops.conv_patch_ok(x, 2, 32, 32, 64, 3, 64)                         # 32 % 3 != 0
+    assert not ops.conv_patch_ok(x[: 2 * 32 * 32 // 4 * 4].view(-1, 16)[: 2 * 32 * 32], 2, 32, 32, 16, 2, 64)   # s*C = 32: not a multiple of 64
+    with pytest.raises(ValueError):
+        ops.conv_patch_fwd(x, 2, 32, 32, 64, 8, torch.zeros(64, 100, device='cuda', dtype=torch.bfloat16))
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('hi,wi,ho,wo,C', [(4, 4, 16, 16, 64), (8, 6, 16, 12, 16), (16, 16, 64, 64, 6), (5, 7, 13, 9, 8), (1, 1, 8, 8, 32),
                                            (32, 40, 128, 160, 6), (7, 9, 20, 31, 5), (16, 300, 8, 150, 6), (3, 3, 9, 9, 2), (1, 5, 4, 20, 6), (9, 300, 18, 600, 3), (2, 1, 8, 4, 8)])
