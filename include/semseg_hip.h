@@ -330,6 +330,18 @@ int ss_terminator_bwd(int dtype, int probs_f32, const void* dprobs, const void* 
  * ss_avgpool: adaptive_avg_pool2d with exact win x win windows (PyramidPoolAgg :527-552), y may be a channel slice of the concat buffer.
  * ss_act: y = act(x) (codes as ss_gemm_nt; the 'ACN' projection :394-409).  ss_inject_fuse: InjectionDotSum.forward :640-673,
  * out = local * bilinear(gact) + bilinear(gemb).  ss_bilinear_add: y += bilinear(x) (UniRes + Sum, modules/heads.py:60-106). */
+/* One inverted-residual block of the token pyramid in one kernel (modules/topformer.py InvertedResidual.forward: conv_in 1x1 + BN + act
+ * -> conv_dw k x k, stride 1 / 2, AutoPadding + BN + act -> conv_out 1x1 + BN (+ x when stride 1 and inc == outc); BatchNorm folded,
+ * inference).  The expanded tensor lives only in LDS.  x [B, H, W, Cin] -> y [B, Ho, Wo, Cout], channels-last bf16.
+ * Host-padded weights (padding zero): w_in [hidp][cinp] bf16 (cinp = Cin rounded up to 16; identity for a block without expansion,
+ * act_in 0), b_in [hidp], w_dw [k*k][hidp] fp32 tap-major, b_dw [hidp], w_out [coutp][hidp] bf16 (coutp = Cout rounded up to 32),
+ * b_out [coutp].  ss_ir_block_ok: 1 when the kernel takes the block (bf16, k 3 / 5, stride 1 / 2, Cin <= 64, Cin and Cout multiples
+ * of 8, hidp a multiple of 32, tile + weights within 80 KiB of LDS so two workgroups share a CU), else 0 -- callers then run the three
+ * launches. */
+int ss_ir_block_ok(int dtype, int Cin, int hidp, int Cout, int k, int s);
+int ss_ir_block_fwd(int dtype, const void* x, void* y, int B, int H, int W, int Cin, int hidp, int Cout, int k, int s, int pad_top,
+                    int pad_left, int Ho, int Wo, const void* w_in, const float* b_in, int act_in, const float* w_dw,
+                    const float* b_dw, int act_dw, const void* w_out, const float* b_out, int residual, hipStream_t stream);
 int ss_im2col_ex(int dtype, const void* x, void* col, int B, int H, int W, int C, int k, int s, int pad_top, int pad_left, int Ho,
                  int Wo, int Kp, hipStream_t stream);
 /* Stem of the token pyramid without the staging pass and the im2col matrix: Conv(3 -> 16, k3, s2, AutoPadding) + folded BN + act

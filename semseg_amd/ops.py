@@ -1013,6 +1013,27 @@ def terminator_bwd(dprobs, prod, wt, bt, B, Hd, Wd, H, W):
 
 
 # ------------------------------------------------------------------ TopFormer helpers
+def ir_block_ok(dtype, Cin, hidp, Cout, k, s):
+    return bool(lib().ss_ir_block_ok(1 if dtype == torch.bfloat16 else 0, Cin, hidp, Cout, k, s))
+
+
+def ir_block_fwd(x, B, H, W, Cout, k, s, pad_top, pad_left, Ho, Wo, w_in, b_in, act_in, w_dw, b_dw, act_dw, w_out, b_out, residual=False):
+    """One fused inverted-residual block (ss_ir_block_fwd): x [B*H*W, Cin] -> y [B*Ho*Wo, Cout]; weights padded as the header says."""
+    dev = _dev(x)
+    rows, Cin, ld = _mat(x, 'x')
+    hidp, cinp = w_in.shape
+    if rows != B * H * W or ld != Cin or not x.is_contiguous():
+        raise ValueError('ir_block_fwd: x must be dense [B*H*W, Cin]')
+    if (cinp != (Cin + 15) // 16 * 16 or tuple(w_dw.shape) != (k * k, hidp) or tuple(w_out.shape) != ((Cout + 31) // 32 * 32, hidp)
+            or w_in.dtype != x.dtype or w_out.dtype != x.dtype or not (w_in.is_contiguous() and w_out.is_contiguous())):
+        raise ValueError('ir_block_fwd: weights are not padded as ss_ir_block_fwd expects')
+    _f32(b_in, 'b_in', hidp), _f32(b_dw, 'b_dw', hidp), _f32(w_dw, 'w_dw', k * k * hidp), _f32(b_out, 'b_out', w_out.shape[0])
+    y = torch.empty((B * Ho * Wo, Cout), dtype=x.dtype, device=dev)
+    check(lib().ss_ir_block_fwd(dt(x), _p(x), _p(y), B, H, W, Cin, hidp, Cout, k, s, pad_top, pad_left, Ho, Wo, _p(w_in), _p(b_in), act_in,
+                                _p(w_dw), _p(b_dw), act_dw, _p(w_out), _p(b_out), int(residual), _stream()))
+    return y
+
+
 def im2col_ex(x, B, H, W, C, k, s, pad_top, pad_left, Ho, Wo):
     dev = _dev(x)
     if not x.is_contiguous() or x.numel() != B * H * W * C:

@@ -20,6 +20,7 @@ Instantiated quirks kept: injection ``global_act`` uses t
 projection is act -> conv -> BN, the pyramid uses ReLU.  Unlike the reference, construction works more than once per process.
 Training mode (batch-statistic BatchNorm + backward) and the RefinerHead are not on the MI355X path yet: they raise.
 """
+import os
 from collections import OrderedDict
 import torch
 from torch import nn, Tensor
@@ -162,6 +163,34 @@ def _w2(w, T):
 class _Plan:
     """Folded, repacked inference weights of one TopFormerModel for one compute dtype (rebuilt when parameters change)."""
 
+    @staticmethod
+    def _fused_block(blk, T):
+        """Weights of one InvertedResidual padded for ss_ir_block_fwd (hidden / output channels to 32, input channels to 16, zeros), or
+        None when the fused kernel does not take the block (wide late blocks stay on the GEMM kernels)."""
+        if os.environ.get('SEMSEG_TOPFORMER_FUSED', '1') == '0':
+            return None
+        dw = blk.net.conv_dw
+        hid, cout = dw.inc, blk.net.conv_out.outc
+        cin = blk.net.conv_in.inc if hasattr(blk.net, 'conv_in') else hid
+        hidp, cinp, coutp = (hid + 31) // 32 * 32, (cin + 15) // 16 * 16, (cout + 31) // 32 * 32
+        if T != torch.bfloat16 or hid > 192 or not ops.ir_block_ok(T, cin, hidp, cout, dw.k, dw.stride):
+            return None
+        dev = dw.net.p_conv.conv.weight.device
+        w_in, b_in = torch.zeros((hidp, cinp), device=dev), torch.zeros(hidp, device=dev)
+        if hasattr(blk.net, 'conv_in'):
+            w, b = blk.net.conv_in.folded()
+            w_in[:hid, :cin], b_in[:hid], act_in = w.reshape(hid, cin), b, blk.net.conv_in.act
+        else:
+            w_in[:hid, :cin], act_in = torch.eye(hid, device=dev), 0              # no expansion: one exact product per element
+        w, b = dw.folded()
+        w_dw, b_dw = torch.zeros((dw.k * dw.k, hidp), device=dev), torch.zeros(hidp, device=dev)
+        w_dw[:, :hid], b_dw[:hid] = w.reshape(hid, dw.k * dw.k).t(), b
+        w, b = blk.net.conv_out.folded()
+        w_out, b_out = torch.zeros((coutp, hidp), device=dev), torch.zeros(coutp, device=dev)
+        w_out[:cout, :hid], b_out[:cout] = w.reshape(cout, hid), b
+        return dict(w_in=w_in.to(T).contiguous(), b_in=b_in, act_in=act_in, w_dw=w_dw.contiguous(), b_dw=b_dw, act_dw=dw.act,
+                    w_out=w_out.to(T).contiguous(), b_out=b_out, cout=cout)
+
     def __init__(self, model, T):
         net = model.backbone.net
         self.T = T
@@ -182,6 +211,7 @@ class _Plan:
                 w, b = blk.net.conv_out.folded()
                 ent['out'] = (_w2(w, T), b)
                 ent['last'] = blk is stage[-1]
+                ent['fused'] = self._fused_block(blk, T)
                 self.blocks.append(ent)
         nh, kd, d = net.num_heads, net.key_dim, net.d
         self.ext = []
@@ -269,12 +299,17 @@ class TopFormerBackBone(nn.Module):
         pyr = OrderedDict()
         names = iter(net.stage_names)
         for ent in plan.blocks:
-            z = ops.gemm_nt(y, ent['in'][0], bias=ent['in'][1], act=RELU) if 'in' in ent else y
             wdw, bdw, k, s = ent['dw']
             p0, _ = auto_pad(k, s)
             ho, wo = h // s, w // s
-            z = ops.dwconvk_fwd(z, wdw, bdw, B, h, w, k, s, p0, p0, ho, wo, act=RELU)
-            y = ops.gemm_nt(z, ent['out'][0], bias=ent['out'][1], res=y if ent['res'] else None)
+            f = ent['fused']
+            if f is not None:                                       # expand -> depthwise -> project in one kernel, the expanded tensor stays in LDS
+                y = ops.ir_block_fwd(y, B, h, w, f['cout'], k, s, p0, p0, ho, wo, f['w_in'], f['b_in'], f['act_in'], f['w_dw'], f['b_dw'],
+                                     f['act_dw'], f['w_out'], f['b_out'], residual=ent['res'])
+            else:
+                z = ops.gemm_nt(y, ent['in'][0], bias=ent['in'][1], act=RELU) if 'in' in ent else y
+                z = ops.dwconvk_fwd(z, wdw, bdw, B, h, w, k, s, p0, p0, ho, wo, act=RELU)
+                y = ops.gemm_nt(z, ent['out'][0], bias=ent['out'][1], res=y if ent['res'] else None)
             h, w = ho, wo
             if ent['last']:
                 pyr[next(names)] = (y, h, w)

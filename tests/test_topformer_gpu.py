@@ -240,3 +240,75 @@ def test_topformer_b_full_size_properties(head):
         assert float((inner - inner[:, :1, :1]).abs().max()) <= 2e-2 * float(inner.abs().max())
     else:
         assert bool(torch.isfinite(flat.float()).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cin,expand,cout,k,s,hw', [(16, 1, 16, 3, 1, (40, 56)), (16, 4, 32, 3, 2, (64, 48)), (32, 3, 32, 3, 1, (33, 21)), (32, 3, 64, 5, 2, (50, 70)),
+                                                    (32, 2, 32, 5, 1, (24, 40)), (16, 4, 24, 3, 2, (38, 26)), (24, 3, 24, 3, 1, (16, 16)), (16, 3, 32, 5, 2, (18, 22))])
+def test_inverted_residual_block_in_one_kernel(cin, expand, cout, k, s, hw):
+    """ss_ir_block_fwd (expand -> depthwise -> project, the expanded tensor only in LDS; modules/topformer.py InvertedResidual, BN folded)
+    against (a) the three launches it replaces, which round at the same two places, and (b) torch fp32 convolutions on the bf16-rounded
+    weights and input (2e-2 bf16 budget).  Covers every stage-1 / stage-2 geometry of TopFormer-T / S / B, odd sizes, both paddings."""
+    from semseg_amd import ops
+    from semseg_amd.topformer import InvertedResidual, _Plan, auto_pad, RELU
+    import torch.nn.functional as F
+    T = torch.bfloat16
+    torch.manual_seed(k * 100 + cin + cout)
+    blk = det_fill_(InvertedResidual(cin, cout, k, s, expand)).cuda().eval()
+    for m in blk.modules():                                   # BatchNorm statistics that do something
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 1.5)
+    f = _Plan._fused_block(blk, T)
+    assert f is not None
+    assert _Plan._fused_block(det_fill_(InvertedResidual(64, 64, 5, 1, 3)).cuda().eval(), T) is None      # 192 hidden channels: tile + weights exceed the LDS share
+    B, (H, W) = 2, hw
+    x = torch.randn(B * H * W, cin, device='cuda').to(T)
+    p0, _ = auto_pad(k, s)
+    ho, wo = H // s, W // s
+    y = ops.ir_block_fwd(x, B, H, W, cout, k, s, p0, p0, ho, wo, f['w_in'], f['b_in'], f['act_in'], f['w_dw'], f['b_dw'], f['act_dw'], f['w_out'],
+                         f['b_out'], residual=blk.residual_connect)
+    # (a) the three launches
+    from semseg_amd.topformer import _w2
+    z = x
+    if expand != 1:
+        w, b = blk.net.conv_in.folded()
+        z = ops.gemm_nt(x, _w2(w, T), bias=b, act=RELU)
+    w, b = blk.net.conv_dw.folded()
+    C = w.shape[0]
+    z = ops.dwconvk_fwd(z, ops.transpose_cast(w.reshape(C, k * k).contiguous(), torch.float32), b, B, H, W, k, s, p0, p0, ho, wo, act=RELU)
+    w, b = blk.net.conv_out.folded()
+    y3 = ops.gemm_nt(z, _w2(w, T), bias=b, res=x if blk.residual_connect else None)
+    assert y.shape == y3.shape and rel(y, y3) < 4e-3          # same rounding points; summation order inside the products differs
+    # (b) torch fp32 on the rounded operands
+    xi = x.float().view(B, H, W, cin).permute(0, 3, 1, 2)
+    t = xi
+    if expand != 1:
+        w, b = blk.net.conv_in.folded()
+        t = F.relu(F.conv2d(t, w.to(T).float(), b))
+    w, b = blk.net.conv_dw.folded()
+    total = (k - 1) - (s - 1)
+    t = F.relu(F.conv2d(F.pad(t, (total // 2, total - total // 2, total // 2, total - total // 2)), w, b, stride=s, groups=w.shape[0]))
+    w, b = blk.net.conv_out.folded()
+    t = F.conv2d(t, w.to(T).float(), b)
+    if blk.residual_connect:
+        t = t + xi
+    assert rel_l2(y.float().view(B, ho, wo, cout).permute(0, 3, 1, 2), t) < 2e-2
+
+
+@pytest.mark.gpu
+def test_fused_pyramid_blocks_equal_the_three_launch_pyramid(monkeypatch):
+    from semseg_amd.topformer import TopFormerModel
+    from semseg_amd.runtime import set_compute_dtype
+    x = det_input('top.x', (2, 3, 128, 192)).cuda()
+    set_compute_dtype(torch.bfloat16)
+    try:
+        net = det_fill_(TopFormerModel(6, 'B')).cuda().eval()
+        fused = net(x)
+        assert any(e['fused'] is not None for e in next(iter(net.backbone._plans.values()))[1].blocks)
+        monkeypatch.setenv('SEMSEG_TOPFORMER_FUSED', '0')
+        net.backbone._plans = {}
+        plain = net(x)
+        assert all(e['fused'] is None for e in next(iter(net.backbone._plans.values()))[1].blocks)
+    finally:
+        set_compute_dtype(None)
+    assert rel_l2(fused, plain) < 1e-2
