@@ -357,6 +357,12 @@ int ss_inject_fuse(int dtype, const void* local, int64_t ldl, const void* gact, 
                    int64_t ldo, int B, int hl, int wl, int hg, int wg, int C, hipStream_t stream);
 int ss_bilinear_add(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
                     hipStream_t stream);
+/* InjectionDotSum of the finest stage (modules/topformer.py:640-673) and the SimpleHead's UniRes + Sum over the other stages
+ * (modules/heads.py:60-106,120-170) in one pass: out = local * bilinear(gact) + bilinear(gemb) + sum_i bilinear(extra_i), fp32 until the
+ * one rounding.  extra / extra_ld / extra_h / extra_w: HOST arrays of n_extra (0..3) device pointers, row strides and map sizes. */
+int ss_inject_fuse_sum(int dtype, const void* local, int64_t ldl, const void* gact, int64_t lda, const void* gemb, int64_t lde,
+                       int n_extra, const void* const* extra, const int64_t* extra_ld, const int* extra_h, const int* extra_w, void* out,
+                       int64_t ldo, int B, int hl, int wl, int hg, int wg, int C, hipStream_t stream);
 
 /* ---- TopFormer RefinerHead, inference (modules/heads.py:22-39 SimpleAttention, :42-60 AttentionUniRes, :173-269 RefinerHead;
  * core/models.py:52-72,99-115).  Token matrices [images * rows_per_image, C], all reductions in a fixed order.

@@ -56,6 +56,39 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, i
     }
 }
 
+// Large windows of narrow maps (PyramidPoolAgg of the first stages: 16 x 16 windows of 32 channels): a thread per output chunk walks
+// win^2 far-apart pixels and only B*ho*wo*C/8 threads exist.  Here a WAVE owns a window: lane = (row lane, 8-channel chunk), a lane sums its
+// rows' pixels (consecutive chunk lanes read a pixel's contiguous channels), the row lanes are combined by a fixed butterfly.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_wave_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int B, int H, int W,
+                                                           int C, int win) {
+    const int chunks = C / 8, dyl = 64 / chunks, ho = H / win, wo = W / win;
+    const int lane = threadIdx.x & 63, ch = lane % chunks, dl = lane / chunks;
+    const int64_t nwin = (int64_t)B * ho * wo, wpb = blockDim.x >> 6;
+    const float inv = 1.f / (win * win);
+    for (int64_t p = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); p < nwin; p += (int64_t)gridDim.x * wpb) {
+        const int ox = (int)(p % wo); const int64_t q = p / wo; const int oy = (int)(q % ho); const int64_t b = q / ho;
+        F8 acc = zero8();
+        for (int dy = dl; dy < win; dy += dyl) {
+            const T* row = x + ((b * H + oy * win + dy) * W + (int64_t)ox * win) * ldx + ch * 8;
+#pragma unroll 4
+            for (int dx = 0; dx < win; ++dx) {
+                const F8 v = load8(row + dx * ldx);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc.v[e] += v.v[e];
+            }
+        }
+        for (int off = chunks; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc.v[e] += __shfl_xor(acc.v[e], off, 64);
+        if (dl == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc.v[e] *= inv;
+            store8(y + p * ldy + ch * 8, acc);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n8, int act) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -91,6 +124,96 @@ __global__ __launch_bounds__(256) void inject_fuse_kernel(const T* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.v[e] = l.v[e] * a.v[e] + g.v[e];
         store8(out + p * ldo + c, o);
+    }
+}
+
+// out = local * up(ga) + up(ge) + sum_i up(extra_i): the injection of the finest stage and the SimpleHead's UniRes + Sum over the other
+// stages in one pass over the finest map (the sum used to be three read-modify-write passes over it); fp32 until the one rounding.
+// A workgroup walks output rows: the vertical taps of every source are per-row constants, a thread owns 8 channels of a pixel, the four
+// taps enter with their products l_y * l_x as packed fp32 fmas (bf16 pairs widen with one shift and one mask), and the flat index is
+// decomposed by multiply-shift (the 64-bit divisions of a flat grid cost more than the arithmetic).
+struct UpSrc { const void* p; int64_t ld; int h, w; float sh, sw; };       // sh, sw: source / destination size
+struct UpSrc3 { UpSrc s[3]; int n; };
+
+template <typename T> struct Raw8;                               // 8 consecutive elements as loaded (the widening waits until they are used)
+template <> struct Raw8<bf16> { bf16x8 v; __device__ __forceinline__ void load(const bf16* p) { v = *(const bf16x8*)p; }
+    __device__ __forceinline__ void widen(floatx2 (&o)[4]) const { union { bf16x8 b; unsigned w[4]; } u; u.b = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = floatx2{__uint_as_float(u.w[e] << 16), __uint_as_float(u.w[e] & 0xffff0000u)}; } };
+template <> struct Raw8<float> { floatx4 a, b; __device__ __forceinline__ void load(const float* p) { a = *(const floatx4*)p; b = *(const floatx4*)(p + 4); }
+    __device__ __forceinline__ void widen(floatx2 (&o)[4]) const { o[0] = floatx2{a[0], a[1]}; o[1] = floatx2{a[2], a[3]}; o[2] = floatx2{b[0], b[1]}; o[3] = floatx2{b[2], b[3]}; } };
+// the four taps of one bilinear sample: loads first (all samples of a pixel are requested before any is used), weights l_y * l_x
+template <typename T> struct Quad {
+    Raw8<T> t[4]; float w[4];
+    __device__ __forceinline__ void load(const T* r0, const T* r1, int x0, int x1, float ly0, float ly1, float lx0, float lx1) {   // 32-bit in-row offsets: uniform base + lane offset
+        t[0].load(r0 + x0); t[1].load(r0 + x1); t[2].load(r1 + x0); t[3].load(r1 + x1);
+        w[0] = ly0 * lx0; w[1] = ly0 * lx1; w[2] = ly1 * lx0; w[3] = ly1 * lx1;
+    }
+    __device__ __forceinline__ void acc(floatx2 (&o)[4]) const {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            floatx2 v[4]; t[k].widen(v);
+            const floatx2 wk = {w[k], w[k]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __builtin_elementwise_fma(v[e], wk, o[e]);
+        }
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void inject_fuse_sum_kernel(const T* __restrict__ local, int64_t ldl, const T* __restrict__ ga, int64_t lda,
+        const T* __restrict__ ge, int64_t lde, UpSrc3 ex, T* __restrict__ out, int64_t ldo, int B, int hl, int wl, int hg, int wg, int C,
+        FastDiv d_chunks, FastDiv d_hl) {
+    const int chunks = C / 8, items = wl * chunks;
+    const float sh = (float)hg / hl, sw = (float)wg / wl;
+    // workgroups bid, bid + 8, ... share an XCD and its L2: each XCD takes a contiguous run of output rows, whose neighbours read the same
+    // source rows (spread round-robin, every L2 fetched every source row)
+    const int nrow = B * hl, per = (nrow + 7) >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = (gridDim.x + 7 - xcd) >> 3;
+    for (int r = slot; r < per; r += slots) {
+        const int row = xcd * per + r;
+        if (row >= nrow) break;
+        const int b = (int)fdiv((unsigned)row, d_hl), oy = row - b * hl;
+        const Tap ty = tap_of(oy, sh, hg);
+        const T* ga0 = ga + ((int64_t)(b * hg + ty.i0) * wg) * lda; const T* ga1 = ga + ((int64_t)(b * hg + ty.i1) * wg) * lda;
+        const T* ge0 = ge + ((int64_t)(b * hg + ty.i0) * wg) * lde; const T* ge1 = ge + ((int64_t)(b * hg + ty.i1) * wg) * lde;
+        // per-row constants of the extra sources: vertical taps, row pointers, horizontal scale
+        const T* er0[3]; const T* er1[3]; float el0[3], el1[3], esw[3]; int eld[3];
+        const int ilda = (int)lda, ilde = (int)lde, ildl = (int)ldl, ildo = (int)ldo;
+        const T* lrow = local + (int64_t)row * wl * ldl; T* orow = out + (int64_t)row * wl * ldo;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const UpSrc& u = ex.s[k < ex.n ? k : 0];
+            const Tap uy = tap_of(oy, ex.n ? u.sh : 1.f, ex.n ? u.h : 1);
+            er0[k] = (const T*)u.p + ((int64_t)(b * u.h + uy.i0) * u.w) * u.ld; er1[k] = (const T*)u.p + ((int64_t)(b * u.h + uy.i1) * u.w) * u.ld;
+            el0[k] = uy.l0; el1[k] = uy.l1; esw[k] = u.sw; eld[k] = (int)u.ld;
+        }
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int ox = (int)fdiv((unsigned)it, d_chunks), c = (it - ox * chunks) * 8;
+            const Tap tx = tap_of(ox, sw, wg);
+            Quad<T> qa, qe, qx[3];
+            Raw8<T> lr;
+            qa.load(ga0, ga1, tx.i0 * ilda + c, tx.i1 * ilda + c, ty.l0, ty.l1, tx.l0, tx.l1);
+            qe.load(ge0, ge1, tx.i0 * ilde + c, tx.i1 * ilde + c, ty.l0, ty.l1, tx.l0, tx.l1);
+            lr.load(lrow + (ox * ildl + c));
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < ex.n) {
+                    const UpSrc& u = ex.s[k];
+                    const Tap ux = tap_of(ox, esw[k], u.w);
+                    qx[k].load(er0[k], er1[k], ux.i0 * eld[k] + c, ux.i1 * eld[k] + c, el0[k], el1[k], ux.l0, ux.l1);
+                }
+            floatx2 act[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, o[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, l[4];
+            qa.acc(act); qe.acc(o); lr.widen(l);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __builtin_elementwise_fma(l[e], act[e], o[e]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < ex.n) qx[k].acc(o);
+            F8 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { r.v[2 * e] = o[e][0]; r.v[2 * e + 1] = o[e][1]; }
+            store8(orow + (ox * ildo + c), r);
+        }
     }
 }
 
@@ -211,6 +334,13 @@ extern "C" int ss_im2col_ex(int dtype, const void* x, void* col, int B, int H, i
 extern "C" int ss_avgpool(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C, int win, hipStream_t stream) {
     SS_CHECK(x && y && B > 0 && win > 0 && H % win == 0 && W % win == 0 && C > 0 && C % 8 == 0 && ldx >= C && ldy >= C && ok8(x, ldx) && ok8(y, ldy),
              "ss_avgpool: need H, W multiples of the window, C %% 8 == 0, 16-byte aligned rows (H=%d W=%d win=%d C=%d)", H, W, win, C);
+    const int chunks = C / 8;
+    if (win >= 4 && chunks <= 16 && (chunks & (chunks - 1)) == 0) {          // a wave per window
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((avgpool_wave_kernel<T>), dim3(tf_blocks((int64_t)B * (H / win) * (W / win) * 64)), dim3(256), 0, stream,
+                                              (const T*)x, ldx, (T*)y, ldy, B, H, W, C, win));
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
     SS_DISPATCH(dtype, hipLaunchKernelGGL((avgpool_kernel<T>), dim3(tf_blocks((int64_t)B * (H / win) * (W / win) * (C / 8))), dim3(256), 0, stream,
                                           (const T*)x, ldx, (T*)y, ldy, B, H, W, C, win));
     SS_LAUNCH_CHECK();
@@ -229,6 +359,34 @@ extern "C" int ss_inject_fuse(int dtype, const void* local, int64_t ldl, const v
              "ss_inject_fuse: rows must be 16-byte aligned");
     SS_DISPATCH(dtype, hipLaunchKernelGGL((inject_fuse_kernel<T>), dim3(tf_blocks((int64_t)B * hl * wl * (C / 8))), dim3(256), 0, stream,
                                           (const T*)local, ldl, (const T*)gact, lda, (const T*)gemb, lde, (T*)out, ldo, B, hl, wl, hg, wg, C));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_inject_fuse_sum(int dtype, const void* local, int64_t ldl, const void* gact, int64_t lda, const void* gemb, int64_t lde,
+                                  int n_extra, const void* const* extra, const int64_t* extra_ld, const int* extra_h, const int* extra_w, void* out,
+                                  int64_t ldo, int B, int hl, int wl, int hg, int wg, int C, hipStream_t stream) {
+    SS_CHECK(local && gact && gemb && out && B > 0 && hl > 0 && wl > 0 && hg > 0 && wg > 0 && C > 0 && C % 8 == 0, "ss_inject_fuse_sum: bad arguments");
+    SS_CHECK(ok8(local, ldl) && ok8(gact, lda) && ok8(gemb, lde) && ok8(out, ldo) && ldl >= C && lda >= C && lde >= C && ldo >= C,
+             "ss_inject_fuse_sum: rows must be 16-byte aligned");
+    SS_CHECK(n_extra >= 0 && n_extra <= 3 && (n_extra == 0 || (extra && extra_ld && extra_h && extra_w)), "ss_inject_fuse_sum: 0..3 extra sources");
+    UpSrc3 ex{};
+    ex.n = n_extra;
+    for (int k = 0; k < n_extra; ++k) {
+        SS_CHECK(extra[k] && ok8(extra[k], extra_ld[k]) && extra_ld[k] >= C && extra_h[k] > 0 && extra_w[k] > 0, "ss_inject_fuse_sum: bad extra source %d", k);
+        ex.s[k].p = extra[k]; ex.s[k].ld = extra_ld[k]; ex.s[k].h = extra_h[k]; ex.s[k].w = extra_w[k];
+        ex.s[k].sh = (float)extra_h[k] / hl; ex.s[k].sw = (float)extra_w[k] / wl;
+    }
+    SS_CHECK((int64_t)B * hl < (1LL << 31) && (int64_t)wl * (C / 8) < (1LL << 31), "ss_inject_fuse_sum: map too large");
+    {   // in-row offsets are 32-bit
+        int64_t mx = (int64_t)wl * (ldl > ldo ? ldl : ldo), g = (int64_t)wg * (lda > lde ? lda : lde);
+        if (g > mx) mx = g;
+        for (int k = 0; k < n_extra; ++k) if ((int64_t)extra_w[k] * extra_ld[k] > mx) mx = (int64_t)extra_w[k] * extra_ld[k];
+        SS_CHECK(mx < (1LL << 31), "ss_inject_fuse_sum: a map row exceeds 2^31 elements");
+    }
+    const int64_t rows = (int64_t)B * hl;
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((inject_fuse_sum_kernel<T>), dim3((unsigned)(rows < 65536 ? rows : 65536)), dim3(256), 0, stream,
+                                          (const T*)local, ldl, (const T*)gact, lda, (const T*)gemb, lde, ex, (T*)out, ldo, B, hl, wl, hg, wg, C,
+                                          fast_div((unsigned)(C / 8)), fast_div((unsigned)hl)));
     SS_LAUNCH_CHECK();
     return 0;
 }

@@ -1094,6 +1094,30 @@ def inject_fuse(local, gact, gemb, B, hl, wl, hg, wg):
     return out
 
 
+def inject_fuse_sum(local, gact, gemb, B, hl, wl, hg, wg, extra):
+    """local * up(gact) + up(gemb) + sum of up(t) over extra = [(t [B*h*w, C], h, w), ...] (at most 3), one pass."""
+    import ctypes
+    dev = _dev(local)
+    rows, C, ldl = _mat(local, 'local')
+    ra, Ca, lda = _mat(gact, 'gact')
+    re_, Ce, lde = _mat(gemb, 'gemb')
+    if rows != B * hl * wl or ra != B * hg * wg or re_ != ra or Ca != C or Ce != C or gact.dtype != local.dtype or gemb.dtype != local.dtype:
+        raise ValueError('inject_fuse_sum: bad shapes')
+    n = len(extra)
+    if n > 3:
+        raise ValueError('inject_fuse_sum: at most 3 extra sources')
+    ptrs, lds, hs, ws = (ctypes.c_void_p * 3)(), (ctypes.c_int64 * 3)(), (ctypes.c_int * 3)(), (ctypes.c_int * 3)()
+    for k, (t, h, w) in enumerate(extra):
+        r, Ct, ldt = _mat(t, 'extra')
+        if r != B * h * w or Ct != C or t.dtype != local.dtype:
+            raise ValueError('inject_fuse_sum: bad extra source')
+        ptrs[k], lds[k], hs[k], ws[k] = t.data_ptr(), ldt, h, w
+    out = torch.empty((rows, C), dtype=local.dtype, device=dev)
+    check(lib().ss_inject_fuse_sum(dt(local), _p(local), ldl, _p(gact), lda, _p(gemb), lde, n, ptrs, lds, hs, ws, _p(out), C, B, hl, wl, hg, wg, C,
+                                   _stream()))
+    return out
+
+
 def bilinear_add(x, y, B, hi, wi, ho, wo):
     """y [B*ho*wo, C] += bilinear(x [B*hi*wi, C])."""
     _dev(x)

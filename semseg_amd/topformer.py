@@ -283,8 +283,9 @@ class TopFormerBackBone(nn.Module):
         self._plans = {}
         return super().train(mode)
 
-    def _run(self, x, plan):
-        """x: fp32 NCHW image -> OrderedDict stage -> (tokens [B*h*w, C], h, w)."""
+    def _run(self, x, plan, sum_into_first=False):
+        """x: fp32 NCHW image -> OrderedDict stage -> (tokens [B*h*w, C], h, w).  sum_into_first: the first (finest) stage's entry is
+        the SimpleHead's UniRes + Sum of ALL stages (modules/heads.py:60-106), formed inside that stage's injection pass."""
         net, T = self.net, plan.T
         B, cin, H, W = x.shape
         pt, _ = auto_pad(3, 2)
@@ -331,16 +332,26 @@ class TopFormerBackBone(nn.Module):
             z = ops.gemm_nt(tok, e['pre'][0], bias=e['pre'][1])
             z = ops.dwconvk_fwd(z, e['dw'][0], e['dw'][1], B, hg, wg, 3, 1, 1, 1, hg, wg, act=RELU6)
             tok = ops.gemm_nt(z, e['post'][0], bias=e['post'][1], res=tok)
-        out, off = OrderedDict(), 0
+        offs, off = {}, 0
         for name, c in zip(net.stage_names, net.channel_splits):
-            f, ph, pw = pyr[name]
-            wts, xg = plan.inj[name], tok[:, off:off + c]
+            offs[name] = (off, c)
             off += c
+        res = {}
+        order = list(net.stage_names)
+        if sum_into_first:                                          # the finest stage last: its injection also takes the other stages' maps
+            order = order[1:] + order[:1]
+        for name in order:
+            f, ph, pw = pyr[name]
+            o, c = offs[name]
+            wts, xg = plan.inj[name], tok[:, o:o + c]
             local = ops.gemm_nt(f, wts['local_embedding'][0], bias=wts['local_embedding'][1])
             ga = ops.gemm_nt(xg, wts['global_act'][0], bias=wts['global_act'][1], act=RELU6)
             ge = ops.gemm_nt(xg, wts['global_embedding'][0], bias=wts['global_embedding'][1])
-            out[name] = (ops.inject_fuse(local, ga, ge, B, ph, pw, hg, wg), ph, pw)
-        return out
+            if sum_into_first and name == net.stage_names[0]:
+                res[name] = (ops.inject_fuse_sum(local, ga, ge, B, ph, pw, hg, wg, [res[n] for n in net.stage_names[1:]]), ph, pw)
+            else:
+                res[name] = (ops.inject_fuse(local, ga, ge, B, ph, pw, hg, wg), ph, pw)
+        return OrderedDict((name, res[name]) for name in net.stage_names)
 
     @staticmethod
     def _fingerprint(model):
@@ -485,7 +496,9 @@ class TopFormerModel(nn.Module):
         """Backbone + head + classifier -> logits [B*h4*w4, round8(nc)] at the finest stage's size (caller holds no_grad)."""
         b = x.shape[0]
         plan = self.backbone._plan_for(self, x)
-        feats = list(self.backbone._run(x, plan).values())
+        nst = len(self.backbone.net.stage_names)
+        fused_sum = isinstance(self.head, SimpleHead) and self.fusion == 'sum' and 1 < nst <= 4
+        feats = list(self.backbone._run(x, plan, sum_into_first=fused_sum).values())
         h4, w4 = max(f[1] for f in feats), max(f[2] for f in feats)         # UniRes target: the largest map (modules/heads.py:78-82)
         if isinstance(self.head, RefinerHead):
             logits4 = self._refiner(plan, feats, b, h4, w4)
@@ -493,9 +506,10 @@ class TopFormerModel(nn.Module):
             if self.fusion == 'sum':
                 if (feats[0][1], feats[0][2]) != (h4, w4):
                     raise ValueError('TopFormerModel: the first stage must be the finest map')
-                acc = feats[0][0]
-                for t, h, w in feats[1:]:
-                    ops.bilinear_add(t, acc, b, h, w, h4, w4)
+                acc = feats[0][0]                                           # already the sum over the stages when fused_sum
+                if not fused_sum:
+                    for t, h, w in feats[1:]:
+                        ops.bilinear_add(t, acc, b, h, w, h4, w4)
             else:                                                           # Concat(dim=1): stage g fills channel slice g
                 C = feats[0][0].shape[1]
                 acc = torch.empty((b * h4 * w4, C * len(feats)), dtype=plan.T, device=x.device)

@@ -312,3 +312,43 @@ def test_fused_pyramid_blocks_equal_the_three_launch_pyramid(monkeypatch):
     finally:
         set_compute_dtype(None)
     assert rel_l2(fused, plain) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C,win,hw', [(32, 16, (64, 96)), (64, 8, (32, 48)), (16, 4, (16, 8)), (24, 16, (32, 32)), (160, 2, (8, 12)), (128, 4, (16, 16))])
+def test_avgpool_window_kernels_vs_torch(dtype, C, win, hw):
+    """ss_avgpool (PyramidPoolAgg's adaptive_avg_pool2d with exact windows, modules/topformer.py:527-552): the wave-per-window kernel
+    (power-of-two chunk counts, windows >= 4) and the thread-per-chunk kernel, into a channel slice of a wider buffer."""
+    import torch.nn.functional as F
+    from semseg_amd import ops
+    B, (H, W) = 3, hw
+    x = torch.randn(B, C, H, W)
+    xr = x.to(dtype).float()
+    ref = F.avg_pool2d(xr, win).permute(0, 2, 3, 1).reshape(-1, C)
+    xd = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda().to(dtype)
+    buf = torch.zeros((B * (H // win) * (W // win), C + 16), device='cuda', dtype=dtype)
+    ops.avgpool(xd, B, H, W, win, out=buf[:, 8:8 + C])
+    assert rel(buf[:, 8:8 + C], ref) < (1e-6 if dtype == torch.float32 else 4e-3)
+    assert float(buf[:, :8].abs().max()) == 0 and float(buf[:, 8 + C:].abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_inject_fuse_sum_equals_injection_plus_upsampled_adds(dtype):
+    """ss_inject_fuse_sum: the finest stage's InjectionDotSum and the SimpleHead's UniRes + Sum in one pass == ss_inject_fuse followed by
+    ss_bilinear_add per stage (fp32: same arithmetic; bf16: one rounding instead of four, so within the bf16 budget of the longer chain)."""
+    from semseg_amd import ops
+    B, C, (hl, wl), (hg, wg) = 2, 64, (32, 48), (4, 6)
+    g = torch.Generator().manual_seed(3)
+    mk = lambda *s: torch.randn(*s, generator=g).cuda().to(dtype)
+    local, ga, ge = mk(B * hl * wl, C), mk(B * hg * wg, C), mk(B * hg * wg, C)
+    extra = [(mk(B * 16 * 24, C), 16, 24), (mk(B * 8 * 12, C), 8, 12), (mk(B * 4 * 6, C), 4, 6)]
+    for n in (0, 1, 3):
+        fused = ops.inject_fuse_sum(local, ga, ge, B, hl, wl, hg, wg, extra[:n])
+        acc = ops.inject_fuse(local, ga, ge, B, hl, wl, hg, wg)
+        for t, h, w in extra[:n]:
+            ops.bilinear_add(t, acc, B, h, w, hl, wl)
+        assert rel(fused, acc) < (2e-6 if dtype == torch.float32 else 1.5e-2), n
+    with pytest.raises(ValueError):
+        ops.inject_fuse_sum(local, ga, ge, B, hl, wl, hg, wg, extra + extra[:1])
