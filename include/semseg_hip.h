@@ -136,6 +136,14 @@ int ss_mit_attn_bwd(int dtype, const void* q, const void* kv, const void* o, con
                     void* dkv, int B, int N, int Nk, int heads, int D, float scale, void* workspace, int64_t ws_bytes,
                     hipStream_t stream);
 
+/* ---- Two chained 1x1 convolutions, the second one narrow: a head's conv + BN + act followed by its classifier (modules/heads.py:120-170
+ * SimpleHead.conv, core/models.py:103-115 classifier).  out2[M, N2] = act(A[M,K] . B[256,K]^T + bias) . W2[N2,256]^T; the 256-wide
+ * activation stays in the GEMM's LDS tile and is never written.  ss_gemm_nt_nt_ok: 1 when the tile kernel takes the shape (bf16, N == 256,
+ * K % 64 == 0, K >= 128, N2 <= 32 and a multiple of 4), else 0 -- callers then chain two ss_gemm_nt calls. */
+int ss_gemm_nt_nt_ok(int dtype, int64_t M, int64_t N, int64_t K, int64_t N2);
+int ss_gemm_nt_nt(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, int act, const void* W2,
+                  int64_t ldw2, void* out2, int64_t ldo2, int64_t M, int64_t N, int64_t K, int64_t N2, hipStream_t stream);
+
 /* ---- im2col / col2im (column order ky,kx,c) feeding ss_gemm_*: PatchEmbed conv k7s4p3 / k3s2p1
  * (modules/segformer.py:70-80) and the spatial-reduction conv k=s=sr (:18,28-29).  Kp = k*k*C rounded up to 8. */
 int ss_im2col(int dtype, const void* x, void* col, int B, int H, int W, int C, int k, int s, int pad, int Kp, hipStream_t stream);

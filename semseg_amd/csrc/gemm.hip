@@ -348,6 +348,25 @@ extern "C" int ss_gemm_nt_gelu2(int dtype, const void* A, int64_t lda, const voi
     return ss_gelu_fwd(dtype, Z, G, M * N, stream);
 }
 
+// Two chained 1x1 convolutions where the second is narrow (a segmentation head's conv + BN + act followed by its classifier,
+// modules/heads.py:120-170 + core/models.py:103-115): out2[M, N2] = act(A . B^T + bias) . W2^T with the N = 256 wide intermediate kept in
+// the GEMM's LDS tile (it is neither written nor read back).  ss_gemm_nt_nt_ok says whether the tile kernel takes the shape.
+extern "C" int ss_gemm_nt_nt_ok(int dtype, int64_t M, int64_t N, int64_t K, int64_t N2) {
+    return dtype == SS_BF16 && M >= 256 && N == 256 && K % 64 == 0 && K >= 128 && K < (1LL << 30) && N2 > 0 && N2 <= 32 && N2 % 4 == 0 && cdiv(M, 256) < 2147483647LL;
+}
+extern "C" int ss_gemm_nt_nt(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, int act, const void* W2,
+                             int64_t ldw2, void* out2, int64_t ldo2, int64_t M, int64_t N, int64_t K, int64_t N2, hipStream_t stream) {
+    SS_CHECK(A && B && W2 && out2 && ss_gemm_nt_nt_ok(dtype, M, N, K, N2), "ss_gemm_nt_nt: needs bf16, N == 256, K a multiple of 64 >= 128, N2 <= 32 (multiple of 4)");
+    SS_CHECK(act >= 0 && act <= 5, "ss_gemm_nt_nt: act must be 0..5");
+    SS_CHECK(lda >= K && ldb >= K && ldw2 >= N && ldo2 >= N2 && lda % 8 == 0 && ldb % 8 == 0 && ldw2 % 8 == 0 && ldo2 % 4 == 0 && aligned16(A) && aligned16(B)
+             && aligned16(W2) && (((uintptr_t)out2) & 7) == 0 && (!bias || aligned16(bias)), "ss_gemm_nt_nt: operands must be aligned (16 bytes; out2 rows 8 bytes)");
+    FastGemm f{};
+    f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = nullptr; f.M = M; f.N = (int)N; f.K = K; f.lda = lda; f.ldb = ldb; f.ldc = N;
+    f.bias = bias; f.rows_per_scale = 1; f.act = act; f.k_per_split = K;
+    f.w2 = (const bf16*)W2; f.ldw2 = ldw2; f.n2 = (int)N2; f.out2 = (bf16*)out2; f.ldo2 = ldo2;
+    return ss_big_nt2_launch(f, stream);
+}
+
 static int tn_big_enabled() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("SS_GEMM_TN_BIG"); on = !(e && e[0] == '0'); }

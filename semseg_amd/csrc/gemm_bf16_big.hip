@@ -112,6 +112,33 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(FastGemm p) {
     }
     nt_epilogue_dispatch<2, 4>(acc, p, smem, EP, m0, n0, wm * 64, wn * 128, li, lh);
     __syncthreads();
+    if (p.w2) {
+        // second product: the finished bf16 tile [256 rows][256 = all N columns] times w2^T; wave w takes rows 32w .. 32w+31, the lane is
+        // a row again and its first register quads are the n2 <= 32 output columns.  The tile itself is not stored.
+        const int row = wave * 32 + li;
+        const bf16* wp = p.w2 + (int64_t)(li < p.n2 ? li : 0) * p.ldw2 + lh * 8;
+        const char* tp = smem + row * EP + lh * 16;
+        const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        floatx16 a2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+#pragma unroll 4
+        for (int ks = 0; ks < BN / 16; ++ks)
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(li < p.n2 ? *(const bf16x8*)(wp + ks * 16) : zero, *(const bf16x8*)(tp + ks * 32), a2, 0, 0, 0);
+        if (m0 + row < p.M) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 8 * g + 4 * lh;
+                if (c0 < p.n2) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)a2[4 * g + e];
+                    *(bf16x4*)(p.out2 + (m0 + row) * p.ldo2 + c0) = o;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll 4
     for (int ps = 0; ps < BM / RPP; ++ps) {
         int row = ps * RPP + erow;
@@ -263,6 +290,13 @@ bool ss_big_nt_ok(const FastGemm& p) {
     // 84 us there against 105 us on the 128-tile kernel (half the bytes through L1 per flop); with N = 256 or K = 64 it does not pay
     if (p.K < 256 && !(cdiv(p.M, 256) * (p.N / 256) >= 4 * cu_count() && p.N >= 512)) return false;
     return cdiv(p.M, 256) * (p.N / 256) >= 256;
+}
+
+int ss_big_nt2_launch(FastGemm p, hipStream_t st) {
+    p.ntn = 1; p.dbg = 0;
+    hipLaunchKernelGGL(gemm_nt_bf16_256_kernel, dim3((unsigned)cdiv(p.M, 256)), dim3(512), 0, st, p);
+    SS_LAUNCH_CHECK();
+    return 0;
 }
 
 int ss_big_nt_launch(FastGemm p, hipStream_t st) {

@@ -30,6 +30,9 @@ struct FastGemm {
     float* colsum_ws;                       // TN: per-split column sums of A, [nsplit][M] (or null)
     bf16* C2; int64_t ldc2;                 // NT: second output (or null): C2 gets the tile as the epilogue left it, C gets GELU of it
     PatchMap pm;                            // patch-addressed operand (side = 0: none); only the 128-row tile kernels take it
+    // second product on the finished tile (gemm_nt_bf16_256_kernel, N == 256 only): out2[M, n2] = epilogue(A . B^T) . w2[n2, N]^T, n2 <= 32;
+    // C is then not written (the classifier of a 1x1-conv head: the 256-channel activation never reaches memory)
+    const bf16* w2; int64_t ldw2; int n2; bf16* out2; int64_t ldo2;
 };
 
 // Copy-out of one 16-byte chunk of the NT kernels' LDS tile image: plain, or -- when C2 is set -- the pre-activation to C2 and
@@ -58,6 +61,7 @@ bool ss_skinny_tn_ok(const void* B, int64_t ldb, int64_t M, int64_t N);
 int ss_skinny_tn_launch(const FastGemm& p, int nsplit, hipStream_t st);
 bool ss_big_nt_ok(const FastGemm& p);
 int ss_big_nt_launch(FastGemm p, hipStream_t st);
+int ss_big_nt2_launch(FastGemm p, hipStream_t st);      // the two-product form (p.w2 set): always the one-tile-per-workgroup kernel
 bool ss_big_tn_plan(int64_t M, int64_t N, int64_t R, int* nsplit, int64_t* rps);
 bool ss_big_tn_ok(const FastGemm& p, int nsplit);
 int ss_big_tn_launch(FastGemm p, int nsplit, hipStream_t st);

@@ -86,6 +86,23 @@ def gemm_nt(a, b, out=None, bias=None, res=None, rowscale=None, rows_per_scale=0
     return out
 
 
+def gemm_nt_nt(a, w1, bias, act, w2):
+    """act(a @ w1.T + bias) @ w2.T with the [M, 256] intermediate kept on chip (ss_gemm_nt_nt) where the tile kernel takes the shape,
+    else two GEMMs.  w2: [N2, 256], N2 <= 32."""
+    dev = _dev(a)
+    M, K, lda = _mat(a, 'a')
+    N, K1, ldb = _mat(w1, 'w1')
+    N2, Nw, ldw2 = _mat(w2, 'w2')
+    if K1 != K or Nw != N or w1.dtype != a.dtype or w2.dtype != a.dtype:
+        raise ValueError('gemm_nt_nt: shapes / dtypes do not chain')
+    _f32(bias, 'bias', N)
+    if not lib().ss_gemm_nt_nt_ok(dt(a), M, N, K, N2):
+        return gemm_nt(gemm_nt(a, w1, bias=bias, act=act), w2)
+    out = torch.empty((M, N2), dtype=a.dtype, device=dev)
+    check(lib().ss_gemm_nt_nt(dt(a), _p(a), lda, _p(w1), ldb, _p(bias), act, _p(w2), ldw2, _p(out), N2, M, N, K, N2, _stream()))
+    return out
+
+
 def gemm_tn(a, b, out=None, accumulate=False, colsum=False):
     """out[M,N] (fp32) (+)= a[R,M]^T @ b[R,N].  colsum=True -> (out, column sums of a [M] fp32) from the same pass."""
     dev = _dev(a)

@@ -515,8 +515,9 @@ class TopFormerModel(nn.Module):
                 acc = torch.empty((b * h4 * w4, C * len(feats)), dtype=plan.T, device=x.device)
                 for g, (t, h, w) in enumerate(feats):
                     ops.bilinear_fwd(t, b, h, w, h4, w4, out=acc[:, g * C:(g + 1) * C])
-            y = ops.gemm_nt(acc, plan.head[0], bias=plan.head[1], act=RELU6)
-            logits4 = ops.gemm_nt(y, plan.cls)                              # [B*h4*w4, round8(nc)], classifier before the up-sampling
+            # head conv + BN + ReLU6, then the classifier BEFORE the up-sampling: [B*h4*w4, round8(nc)]; where the head is 256 wide the
+            # two products are one kernel and the 256-channel activation is never written
+            logits4 = ops.gemm_nt_nt(acc, plan.head[0], plan.head[1], RELU6, plan.cls)
         return logits4, h4, w4
 
     def _refiner(self, plan, feats, b, h4, w4):

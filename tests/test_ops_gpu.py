@@ -301,6 +301,21 @@ def test_im2col_conv(ops, dtype, C, k, s, pad):
         assert rel(dx.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _gtol(dtype)
 
 
+@pytest.mark.parametrize('M,N,K,N2,act', [(1000, 256, 256, 8, 3), (4096 + 77, 256, 128, 32, 2), (300, 256, 320, 4, 0), (512, 192, 256, 8, 3), (256, 256, 64, 8, 3)])
+def test_gemm_nt_nt_keeps_the_wide_activation_on_chip(ops, M, N, K, N2, act):
+    """ss_gemm_nt_nt: act(a @ w1.T + b) @ w2.T in one kernel (a head's 1x1 conv + BN + act and its classifier, modules/heads.py:120-170,
+    core/models.py:103-115) against the two GEMMs it replaces: the intermediate is rounded to bf16 at the same place, so only the fp32
+    summation order of the second product differs.  Shapes the tile kernel does not take (N != 256, K < 128) run the two GEMMs."""
+    T = torch.bfloat16
+    a, w1, b, w2 = dev(rnd(M, K), T), dev(rnd(N, K, seed=1) / math.sqrt(K), T), dev(rnd(N, seed=2)), dev(rnd(N2, N, seed=3) / math.sqrt(N), T)
+    out = ops.gemm_nt_nt(a, w1, b, act, w2)
+    two = ops.gemm_nt(ops.gemm_nt(a, w1, bias=b, act=act), w2)
+    assert out.shape == (M, N2) and rel(out, two) < 4e-3
+    h = (a.float() @ w1.float().t() + b)
+    h = {0: h, 2: h.clamp(min=0), 3: h.clamp(0, 6)}[act].to(T).float()
+    assert rel(out, h @ w2.float().t()) < 6e-3
+
+
 @pytest.mark.parametrize('B,H,W,C,s,O', [(2, 32, 24, 64, 8, 64), (3, 16, 40, 128, 4, 128), (2, 12, 20, 320, 2, 320), (1, 8, 8, 32, 2, 72),
                                          (2, 64, 64, 96, 2, 192), (5, 24, 8, 16, 4, 8)])
 def test_conv_patch_gemms_without_patch_matrix(ops, B, H, W, C, s, O):
