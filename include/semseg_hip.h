@@ -387,6 +387,12 @@ int ss_image_moments(int dtype, const void* x, int64_t ld, int64_t rows_per_imag
                      float* workspace, int64_t ws_bytes, hipStream_t stream);
 int ss_simam_apply(int dtype, const void* x, int64_t ldx, const float* moments, const float* k, void* y, int64_t ldy,
                    int64_t rows_per_image, int C, int images, hipStream_t stream);
+/* SimAM and the grouped 1x1 conv that consumes it in one kernel (modules/heads.py:27-39 + :200-222): out[p][n] (fp32) =
+ * sum_c w[n][c] * att[p][c], att = ss_simam_apply's output rounded to the compute dtype -- which is then never written.
+ * ss_simam_gemm_ok: 1 for bf16, C a power of two in 64..2048, N <= 32 and a multiple of 4; else callers run ss_simam_apply + ss_gemm_nt. */
+int ss_simam_gemm_ok(int dtype, int C, int N);
+int ss_simam_gemm(int dtype, const void* x, int64_t ldx, const float* moments, const float* k, const void* w, int64_t ldw, float* out,
+                  int64_t ldo, int64_t rows_per_image, int C, int images, int N, hipStream_t stream);
 int ss_refiner_fold(const float* moments, int64_t rows_per_image, int images, int groups, int cg, int pitch, int ncol, float eps, const float* gamma,
                     const float* beta, const float* L, int lrows, int mrows, float* M, float* cvec, hipStream_t stream);
 int ss_image_affine(int out_dtype, const float* in, int64_t ldi, const float* M, const float* cvec, void* out, int64_t ldo,

@@ -114,6 +114,83 @@ extern "C" int ss_simam_apply(int dtype, const void* x, int64_t ldx, const float
     return 0;
 }
 
+// SimAM and the grouped 1x1 conv that consumes it (modules/heads.py:27-39 + :200-222) in one kernel: out[p][n] = sum_c W[n][c] att[p][c],
+// att = x * sigmoid(...) as above.  As two launches the attention map is written and read back (1.07 GB at the finest stage of TopFormer-B,
+// 4 x 2048^2, for 32 MB of output).  A workgroup owns 64 rows of one image: a thread keeps one 8-channel chunk (its mu / inv stay in
+// registers), att is rounded to the compute dtype into an LDS tile -- the value the two-launch form stored -- and waves 0 and 1 multiply
+// the tile by W on the matrix cores (weights as the A operand: the lane is a row, its first register quads the N <= 32 outputs).
+__global__ __launch_bounds__(256) void simam_gemm_kernel(const bf16* __restrict__ x, int64_t ldx, const float* __restrict__ moments,
+        const float* __restrict__ kp, const bf16* __restrict__ w, int64_t ldw, float* __restrict__ out, int64_t ldo, int64_t rows, int C, int N,
+        int tiles_per_image) {
+    extern __shared__ __attribute__((aligned(16))) char tile[];           // [64][C] bf16, pitch C*2 + 16
+    const int PT = C * 2 + 16;
+    const int img = blockIdx.x / tiles_per_image, t = blockIdx.x - img * tiles_per_image;
+    const int64_t r0 = (int64_t)t * 64;                                    // first row of the tile inside the image
+    const int chunks = C >> 3, tid = threadIdx.x;
+    const float k = kp[0], inv_nm1 = 1.f / (float)(rows - 1);
+    const int rpp = 256 / chunks;                                          // rows per pass (chunks divides 256: C in 64 .. 2048, power of two)
+    const int ch = tid % chunks, rl = tid / chunks, c = ch * 8;
+    float mu[8], inv[8];
+    { const F8 m = load8(moments + ((int64_t)img * 2 + 0) * C + c), q = load8(moments + ((int64_t)img * 2 + 1) * C + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { mu[e] = m.v[e]; inv[e] = 1.f / (4.f * (k + q.v[e] * inv_nm1)); } }
+    const bf16* xp = x + ((int64_t)img * rows + r0) * ldx + c;
+#pragma unroll 4
+    for (int r = rl; r < 64; r += rpp) {
+        F8 o = zero8();
+        if (r0 + r < rows) {
+            const F8 v = load8(xp + (int64_t)r * ldx);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v.v[e] - mu[e]; o.v[e] = v.v[e] * sigmoid_f(d * d * inv[e] + 0.5f); }
+        }
+        store8((bf16*)(tile + r * PT) + c, o);
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    if (wave >= 2) return;
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16* wp = w + (int64_t)(li < N ? li : 0) * ldw + lh * 8;
+    const char* tp = tile + (wave * 32 + li) * PT + lh * 16;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int ks = 0; ks < (C >> 4); ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(li < N ? *(const bf16x8*)(wp + ks * 16) : zero, *(const bf16x8*)(tp + ks * 32), acc, 0, 0, 0);
+    const int64_t row = r0 + wave * 32 + li;
+    if (row < rows) {
+        float* op = out + ((int64_t)img * rows + row) * ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n0 = 8 * g + 4 * lh;
+            if (n0 < N) *(floatx4*)(op + n0) = floatx4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        }
+    }
+}
+
+extern "C" int ss_simam_gemm_ok(int dtype, int C, int N) {
+    return dtype == SS_BF16 && C >= 64 && C <= 2048 && (C & (C - 1)) == 0 && N > 0 && N <= 32 && N % 4 == 0;
+}
+
+extern "C" int ss_simam_gemm(int dtype, const void* x, int64_t ldx, const float* moments, const float* k, const void* w, int64_t ldw, float* out,
+                             int64_t ldo, int64_t rows_per_image, int C, int images, int N, hipStream_t stream) {
+    SS_CHECK(x && moments && k && w && out && rows_per_image > 1 && images > 0 && ss_simam_gemm_ok(dtype, C, N),
+             "ss_simam_gemm: needs bf16, C a power of two in 64..2048, N <= 32 and a multiple of 4 (C=%d N=%d)", C, N);
+    SS_CHECK(ldx >= C && ldw >= C && ldo >= N && ldx % 8 == 0 && ldw % 8 == 0 && ldo % 4 == 0 && aligned16(x) && aligned16(w) && aligned16(out) && aligned16(moments),
+             "ss_simam_gemm: operands must be 16-byte aligned");
+    const int64_t tpi = cdiv(rows_per_image, 64);
+    SS_CHECK(tpi * images < (1LL << 31), "ss_simam_gemm: grid too large");
+    const size_t lds = (size_t)64 * (C * 2 + 16);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)simam_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return ss_fail(-2, "ss_simam_gemm: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(simam_gemm_kernel, dim3((unsigned)(tpi * images)), dim3(256), lds, stream, (const bf16*)x, ldx, moments, k, (const bf16*)w, ldw, out, ldo,
+                       rows_per_image, C, N, (int)tpi);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
 // GroupNorm folded into the linear map that follows it.  Input columns: `groups` blocks of `pitch` columns, the first `cg` of each
 // valid (input channel o = g*cg + j sits in column g*pitch + j; the rest, up to `ncol` columns, is padding).  GroupNorm(groups, groups*cg) statistics per
 // image from the per-column moments (mean_g = avg of the column means, var_g = (sum M2_j + n (mean_j - mean_g)^2) / (cg n), biased),

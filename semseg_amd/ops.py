@@ -1178,6 +1178,25 @@ def simam_apply(x, moments, k, images, out=None):
     return out
 
 
+def simam_gemm(x, moments, k, images, w, out=None):
+    """(SimAM(x) rounded to x's dtype) @ w.T -> fp32 [rows, N]; one kernel where ss_simam_gemm takes the shape, else simam_apply + gemm_nt."""
+    dev = _dev(x)
+    rows, C, ldx = _mat(x, 'x')
+    N, Cw, ldw = _mat(w, 'w')
+    if Cw != C or w.dtype != x.dtype or rows % images:
+        raise ValueError('simam_gemm: bad shapes')
+    _f32(moments, 'moments', images * 2 * C), _f32(k, 'k', 1)
+    if out is None:
+        out = torch.empty((rows, N), dtype=torch.float32, device=dev)
+    ro, No, ldo = _mat(out, 'out')
+    if (ro, No) != (rows, N) or out.dtype != torch.float32:
+        raise ValueError('simam_gemm: bad out')
+    if not lib().ss_simam_gemm_ok(dt(x), C, N) or ldo % 4 or out.data_ptr() % 16:
+        return gemm_nt(simam_apply(x, moments, k, images), w, out=out, out_f32=True)
+    check(lib().ss_simam_gemm(dt(x), _p(x), ldx, _p(moments), _p(k), _p(w), ldw, _p(out), ldo, rows // images, C, images, N, _stream()))
+    return out
+
+
 def refiner_fold(moments, rows_per_image, groups, cg, pitch, eps, gamma, beta, L, mrows):
     """GroupNorm(groups, groups*cg) on columns g*pitch + j of an [.., ncol] map, then the fixed map L [lrows, groups*cg]
     ->  (M [images, mrows, ncol], c [images, mrows])."""

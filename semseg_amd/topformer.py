@@ -530,12 +530,12 @@ class TopFormerModel(nn.Module):
         n4 = h4 * w4
         u = torch.empty((b * n4, d * ncp), dtype=torch.float32, device=feats[0][0].device)
         for g, (t, h, w) in enumerate(feats):
-            att = ops.simam_apply(t, ops.image_moments(t, b), plan.k, b)
+            mom = ops.image_moments(t, b)
             dst = u[:, g * ncp:(g + 1) * ncp]
-            if (h, w) == (h4, w4):
-                ops.gemm_nt(att, plan.group_w[g], out=dst, out_f32=True)
+            if (h, w) == (h4, w4):                                         # SimAM + group conv in one kernel: the attention map is not written
+                ops.simam_gemm(t, mom, plan.k, b, plan.group_w[g], out=dst)
             else:
-                ops.bilinear_fwd(ops.gemm_nt(att, plan.group_w[g], out_f32=True), b, h, w, h4, w4, out=dst)
+                ops.bilinear_fwd(ops.simam_gemm(t, mom, plan.k, b, plan.group_w[g]), b, h, w, h4, w4, out=dst)
         m1, c1 = ops.refiner_fold(ops.image_moments(u, b, pre_act=ops.SIGMOID), n4, d, nc, ncp, plan.gn1[2], plan.gn1[0], plan.gn1[1], plan.L1, ncp)
         r = ops.image_affine(u, m1, c1, pre_act=ops.SIGMOID)                   # [b*n4, ncp] fp32, padding columns zero
         if plan.gn2 is not None:

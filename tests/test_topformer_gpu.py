@@ -352,3 +352,21 @@ def test_inject_fuse_sum_equals_injection_plus_upsampled_adds(dtype):
         assert rel(fused, acc) < (2e-6 if dtype == torch.float32 else 1.5e-2), n
     with pytest.raises(ValueError):
         ops.inject_fuse_sum(local, ga, ge, B, hl, wl, hg, wg, extra + extra[:1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,N,rows,images', [(256, 8, 4096, 2), (64, 32, 1000, 3), (128, 4, 77, 1), (96, 8, 256, 2)])
+def test_simam_and_group_conv_in_one_kernel(C, N, rows, images):
+    """ss_simam_gemm == ss_simam_apply (rounded to bf16) followed by ss_gemm_nt with fp32 output: same rounding point, only the fp32
+    summation order of the product differs.  C = 96 (not a power of two) takes the two launches inside the wrapper."""
+    from semseg_amd import ops
+    g = torch.Generator().manual_seed(C + N)
+    x = (torch.randn(images * rows, C, generator=g) * 1.5 + 0.3).cuda().bfloat16()
+    w = (torch.randn(N, C, generator=g) / C ** 0.5).cuda().bfloat16()
+    k = torch.tensor([1e-4], device='cuda')
+    mom = ops.image_moments(x, images)
+    two = ops.gemm_nt(ops.simam_apply(x, mom, k, images), w, out_f32=True)
+    buf = torch.full((images * rows, N + 8), 7.0, device='cuda')
+    one = ops.simam_gemm(x, mom, k, images, w, out=buf[:, 4:4 + N])
+    assert rel(one, two) < 2e-5
+    assert float((buf[:, :4] - 7).abs().max()) == 0 and float((buf[:, 4 + N:] - 7).abs().max()) == 0
