@@ -93,6 +93,19 @@ int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, int64_t ldz
               const float* beta, const float* mask, int64_t rows_per_image, int training, void* dz, int64_t ldo,
               float* dgamma_dbeta, int64_t rows, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
+/* The same three steps for a BatchNorm whose input is a bilinear resize (tnf.interpolate(..., mode='bilinear', align_corners=False),
+ * modules/lawin.py:213-222, followed by ConvModule `cat`'s BatchNorm2d + Mish, lawin.py:101-105) of the coarse map x [B*hi*wi, C]:
+ * the kernels read z = resize(x) through its four taps (the bits ss_bilinear_fwd would store), so the resized [B*ho*wo, C]
+ * tensor is never written.  y, dy and dz are [B*ho*wo, C]; dz is the gradient of the resized map (ss_bilinear_bwd takes it to x). */
+int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo, int C, float eps, float momentum,
+                   float* stats, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* workspace,
+                   int64_t ws_bytes, hipStream_t stream);
+int ss_bn_apply_up(int dtype, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo, const float* stats,
+                   const float* gamma, const float* beta, void* y, int64_t ldy, int C, int act, hipStream_t stream);
+int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo,
+                 const float* stats, const float* gamma, const float* beta, int training, void* dz, int64_t ldo,
+                 float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
+
 /* ---- Mix-FFN depthwise 3x3 (+bias, +GELU) on token layout (modules/segformer.py:44-53,64).
  * w9c: weights repacked tap-major [9][C] fp32.  act: 0 none, 1 GELU(erf).
  * bwd: g = dy*act'(dw(x)+b) (written), dw_db = [10][C] fp32 (9 taps + bias); dx = ss_dwconv3_fwd(g, flipped taps). */

@@ -3,6 +3,7 @@
 // fp32 statistics, deterministic reductions (colreduce.h).
 #include "common.h"
 #include "colreduce.h"
+#include "bilinear.h"
 
 // ------------------------------------------------------------------ LayerNorm
 // One row is handled by `lpr` lanes (power of two), NCH chunks of 8 channels per lane.
@@ -18,6 +19,33 @@ template <> struct Raw8<float> {
     __device__ __forceinline__ void load(const float* p) { a = *(const floatx4*)p; b = *(const floatx4*)(p + 4); }
     __device__ __forceinline__ float get(int e) const { return e < 4 ? a[e & 3] : b[e & 3]; }
 };                       // chunk lanes x row lanes of a 256-thread workgroup (col_geom)
+
+// A BatchNorm input that is the bilinear resize (align_corners = False) of a coarser channels-last map, read through its four
+// taps instead of from a resized copy: row r of the virtual [B*ho*wo, C] matrix is output pixel r, its value the very bits
+// ss_bilinear_fwd would have stored (same taps, same fma order, rounded to T).  The resized tensor -- 4x the map for the x2
+// up-sampling in front of LawinHead's `cat` BatchNorm -- is then never written nor read; the taps come from L1 / L2.
+struct UpGeom { int hi, wi, ho, wo; float sh, sw; FastDiv dwo, dho; };
+template <typename T> struct UpTaps { Raw8<T> a, b, c, d; float y0, y1, x0, x1; };
+template <typename T>
+__device__ __forceinline__ void up_issue(const T* __restrict__ x, int64_t ld, const UpGeom& g, int64_t r, int c, UpTaps<T>& t) {
+    const unsigned q = fdiv((unsigned)r, g.dwo), ox = (unsigned)r - q * (unsigned)g.wo;
+    const unsigned b = fdiv(q, g.dho), oy = q - b * (unsigned)g.ho;
+    const LinTap ty = lin_tap((int)oy, g.sh, g.hi), tx = lin_tap((int)ox, g.sw, g.wi);
+    const T* r0 = x + (((int64_t)b * g.hi + ty.i0) * g.wi) * ld + c;
+    const T* r1 = x + (((int64_t)b * g.hi + ty.i1) * g.wi) * ld + c;
+    t.a.load(r0 + tx.i0 * ld); t.b.load(r0 + tx.i1 * ld); t.c.load(r1 + tx.i0 * ld); t.d.load(r1 + tx.i1 * ld);
+    t.y0 = ty.l0; t.y1 = ty.l1; t.x0 = tx.l0; t.x1 = tx.l1;
+}
+template <typename T>
+__device__ __forceinline__ float up_value(const UpTaps<T>& t, int e) {
+    LinTap ty, tx; ty.l0 = t.y0; ty.l1 = t.y1; tx.l0 = t.x0; tx.l1 = t.x1;
+    return to_f(from_f<T>(bilerp(ty, tx, t.a.get(e), t.b.get(e), t.c.get(e), t.d.get(e))));
+}
+static inline UpGeom up_geom(int hi, int wi, int ho, int wo) {
+    UpGeom g; g.hi = hi; g.wi = wi; g.ho = ho; g.wo = wo; g.sh = (float)hi / ho; g.sw = (float)wi / wo;
+    g.dwo = fast_div((unsigned)wo); g.dho = fast_div((unsigned)ho);
+    return g;
+}
 
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
@@ -254,6 +282,18 @@ template <typename T> struct BnStatF {
     }
 };
 
+// the same sums over the resized map (row 0 of the virtual matrix is pixel (0, 0, 0) = x[0] exactly: its taps weigh 1 and 0)
+template <typename T> struct BnStatUpF {
+    static constexpr int K = 2;
+    const T* x; int64_t ld; UpGeom g;
+    __device__ void operator()(int64_t row, int c0, float (&acc)[2][8]) const {
+        UpTaps<T> t; up_issue<T>(x, ld, g, row, c0, t);
+        F8 s = load8(x + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float d = up_value<T>(t, e) - s.v[e]; acc[0][e] += d; acc[1][e] += d * d; }
+    }
+};
+
 // stats[0][c] = mean, stats[1][c] = rstd (biased variance); running stats updated like nn.BatchNorm2d (unbiased var)
 // 8 channels x 32 row-parts per block (double accumulation, fixed order)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nb, int C, int64_t n, float eps, float momentum,
@@ -302,6 +342,281 @@ extern "C" int ss_bn_stats(int dtype, const void* x, int64_t ld, int64_t rows, i
     return 0;
 }
 
+// ------------------------------------------------------------------ the x2 case (ho = 2 hi, wo = 2 wi) as a column walker
+// The generic kernels above pay four 16-byte taps, two index divisions and a full bilerp per output chunk.  For the exact x2
+// up-sampling of LawinHead's `cat` a thread instead owns ONE input column j and 8 channels and walks down input rows: output
+// columns 2j, 2j+1 take taps (j-1, j) and (j, j+1), output rows 2p, 2p+1 take input rows (p-1, p) and (p, p+1), all clamped at
+// the borders exactly as lin_tap clamps them (a clamped duplicate meets weight 0, or both weights of the same value -- the same
+// bits as the generic formula).  The horizontal lerps of an input row are computed once and serve the four output rows that use
+// it; three lerped rows (p-1, p, p+1) rotate through registers and rows p+2 .. p+4 are in flight: one new input row (4 loads, 2
+// of them the same line) and 2 x 8 x 2 horizontal + 4 x 8 x 2 vertical flops per FOUR output chunks.
+struct Up2Geom { int cpb, xl, groups, xtiles, ystrips, tp, chunks; };
+static inline Up2Geom up2_geom(int B, int hi, int wi, int C) {
+    Up2Geom g; g.chunks = C / 8;
+    int cpb = 1; while (cpb < g.chunks && cpb < 64) cpb <<= 1;
+    g.cpb = cpb; g.xl = 256 / cpb; g.groups = (int)cdiv(g.chunks, cpb);
+    g.xtiles = (int)cdiv(wi, g.xl);
+    int tp = 24;                                           // row pairs per strip (a multiple of 3: the window rotates through 3 slots)
+    while (tp > 6 && (int64_t)B * g.xtiles * cdiv(hi, tp) * g.groups < 4096) tp -= 6;
+    g.tp = tp; g.ystrips = (int)cdiv(hi, tp);
+    return g;
+}
+template <typename T> struct Up2Row { Raw8<T> a0, b0, a1, b1; };
+template <typename T> struct Up2 {
+    const T* base; int64_t rs, oA0, oB0, oA1, oB1; int hi; float l00, l01, l10, l11;
+    __device__ __forceinline__ void init(const T* x, int64_t ld, int hi_, int wi, int img, int j, int c) {
+        const int jc = min(max(j, 0), wi - 1);
+        const LinTap t0 = lin_tap(2 * jc, 0.5f, wi), t1 = lin_tap(2 * jc + 1, 0.5f, wi);
+        hi = hi_; rs = (int64_t)wi * ld; base = x + (int64_t)img * hi * rs + c;
+        oA0 = t0.i0 * ld; oB0 = t0.i1 * ld; oA1 = t1.i0 * ld; oB1 = t1.i1 * ld;
+        l00 = t0.l0; l01 = t0.l1; l10 = t1.l0; l11 = t1.l1;
+    }
+    __device__ __forceinline__ void issue(int row, Up2Row<T>& r) const {
+        const T* p = base + (int64_t)min(max(row, 0), hi - 1) * rs;
+        r.a0.load(p + oA0); r.b0.load(p + oB0); r.a1.load(p + oA1); r.b1.load(p + oB1);
+    }
+    __device__ __forceinline__ void hlerp(const Up2Row<T>& r, float (&h)[2][8]) const {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h[0][e] = fmaf(l01, r.b0.get(e), l00 * r.a0.get(e));
+            h[1][e] = fmaf(l11, r.b1.get(e), l10 * r.a1.get(e));
+        }
+    }
+};
+// the two output rows of pair p from the lerped input rows p-1, p, p+1: z[r][col][e], rounded to T as ss_bilinear_fwd stores them
+template <typename T>
+__device__ __forceinline__ void up2_rows(int p, int hi, const float (&prev)[2][8], const float (&cur)[2][8], const float (&next)[2][8],
+                                         float (&z)[2][2][8]) {
+    const LinTap te = lin_tap(2 * p, 0.5f, hi), to = lin_tap(2 * p + 1, 0.5f, hi);
+#pragma unroll
+    for (int col = 0; col < 2; ++col)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            z[0][col][e] = to_f(from_f<T>(fmaf(te.l1, cur[col][e], te.l0 * prev[col][e])));
+            z[1][col][e] = to_f(from_f<T>(fmaf(to.l1, next[col][e], to.l0 * cur[col][e])));
+        }
+}
+// Shared frame of the walker kernels.  body(p, z) runs once per row pair p in [ps, ps + 3 * ceil((pe - ps) / 3)): pairs >= pe are
+// computed from clamped rows and must be ignored by the body.
+template <typename T, typename F>
+__device__ __forceinline__ void up2_walk(const Up2<T>& U, int ps, int pe, F&& body) {
+    float H[3][2][8]; Up2Row<T> ring[3];
+    { Up2Row<T> r; U.issue(ps - 1, r); U.hlerp(r, H[0]); U.issue(ps, r); U.hlerp(r, H[1]); U.issue(ps + 1, r); U.hlerp(r, H[2]); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) U.issue(ps + 2 + i, ring[i]);
+    for (int p0 = ps; p0 < pe; p0 += 3) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int p = p0 + i;
+            float z[2][2][8];
+            up2_rows<T>(p, U.hi, H[i % 3], H[(i + 1) % 3], H[(i + 2) % 3], z);
+            body(p, z);
+            U.hlerp(ring[i], H[i % 3]);                      // row p + 2 takes the slot of row p - 1
+            U.issue(p + 5, ring[i]);
+        }
+    }
+}
+
+struct Up2Tile { int img, j, ps, pe; bool colok; };
+__device__ __forceinline__ Up2Tile up2_tile(int tile, const Up2Geom& g, int hi, int wi, int xs) {
+    const int per_img = g.xtiles * g.ystrips;
+    Up2Tile t; t.img = tile / per_img; const int rem = tile - t.img * per_img;
+    const int ys = rem / g.xtiles, xt = rem - ys * g.xtiles;
+    t.j = xt * g.xl + xs; t.colok = t.j < wi;
+    t.ps = ys * g.tp; t.pe = min(hi, t.ps + g.tp);
+    return t;
+}
+
+// partial[blockIdx.x][0][c] = sum (z - shift), [1] = sum (z - shift)^2 over this workgroup's tiles, shift = x[0][c]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_up2_kernel(const T* __restrict__ x, int64_t ld, int B, int hi, int wi, int C, Up2Geom g,
+                                                           float* __restrict__ partial) {
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x, cl = tid % g.cpb, xs = tid / g.cpb;
+    const int chunk_raw = blockIdx.y * g.cpb + cl;
+    const bool cok = chunk_raw < g.chunks;
+    const int c = (cok ? chunk_raw : g.chunks - 1) * 8;
+    float acc[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    const F8 sh = load8(x + c);
+    const int ntiles = B * g.xtiles * g.ystrips;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const Up2Tile t = up2_tile(tile, g, hi, wi, xs);
+        Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c);
+        up2_walk<T>(U, t.ps, t.pe, [&](int p, const float (&z)[2][2][8]) {
+            const float live = (t.colok && cok && p < t.pe) ? 1.f : 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int col = 0; col < 2; ++col)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = (z[r][col][e] - sh.v[e]) * live; acc[0][e] += d; acc[1][e] = fmaf(d, d, acc[1][e]); }
+        });
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[k][e];
+        __syncthreads();
+        if (xs == 0 && cok) {
+            float* dst = partial + ((int64_t)blockIdx.x * 2 + k) * C + c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float s = 0.f;
+                for (int q = 0; q < g.xl; ++q) s += red[(q * g.cpb + cl) * 8 + e];
+                dst[e] = s; }
+        }
+    }
+}
+
+// y[2p + r][2j + col] = act(gamma * (z - mean) * rstd + beta)
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bn_apply_up2_kernel(const T* __restrict__ x, int64_t ld, int hi, int wi, const float* __restrict__ stats,
+        const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, int64_t ldy, int C, Up2Geom g) {
+    const int tid = threadIdx.x, cl = tid % g.cpb, xs = tid / g.cpb;
+    const int chunk = blockIdx.y * g.cpb + cl;
+    if (chunk >= g.chunks) return;
+    const int c = chunk * 8;
+    const Up2Tile t = up2_tile(blockIdx.x, g, hi, wi, xs);
+    if (!t.colok) return;
+    F8 sc, sh;
+    { F8 mu = load8(stats + c), rs = load8(stats + C + c), gm = load8(gamma + c), b = load8(beta + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc.v[e] = rs.v[e] * gm.v[e]; sh.v[e] = b.v[e] - mu.v[e] * sc.v[e]; } }
+    const int wo = 2 * wi;
+    T* yb = y + ((int64_t)t.img * 2 * hi * wo + 2 * t.j) * ldy + c;
+    Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c);
+    up2_walk<T>(U, t.ps, t.pe, [&](int p, const float (&z)[2][2][8]) {
+        if (p < t.pe) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int col = 0; col < 2; ++col) {
+                    F8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { float u = fmaf(z[r][col][e], sc.v[e], sh.v[e]); o.v[e] = ACT == 1 ? mish_f(u) : u; }
+                    store8(yb + ((int64_t)(2 * p + r) * wo + col) * ldy, o);
+                }
+        }
+    });
+}
+
+// backward over the resized map: PASS2 = false: partial sums of g and g * xhat; true: dz (the gradient of the resized map)
+template <typename T, int ACT, bool PASS2>
+__global__ __launch_bounds__(256) void bn_bwd_up2_kernel(const T* __restrict__ dy, int64_t ldd, const T* __restrict__ x, int64_t ld, int B, int hi, int wi,
+        const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ coef,
+        T* __restrict__ dz, int64_t ldo, float* __restrict__ partial, int C, Up2Geom g) {
+    __shared__ float red[PASS2 ? 1 : 256 * 8];
+    const int tid = threadIdx.x, cl = tid % g.cpb, xs = tid / g.cpb;
+    const int chunk_raw = blockIdx.y * g.cpb + cl;
+    const bool cok = chunk_raw < g.chunks;
+    const int c = (cok ? chunk_raw : g.chunks - 1) * 8;
+    float acc[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    F8 xs_, xo, gm, bt, k0, k1, k2;                          // xhat = z * xs + xo;  dz = k0 * g + k1 + xhat * k2
+    { F8 mu = load8(stats + c), rs = load8(stats + C + c);
+      gm = load8(gamma + c); bt = load8(beta + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xs_.v[e] = rs.v[e]; xo.v[e] = -mu.v[e] * rs.v[e]; }
+      if (PASS2) { F8 c1 = load8(coef + c), c2 = load8(coef + C + c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { k0.v[e] = gm.v[e] * rs.v[e]; k1.v[e] = -k0.v[e] * c1.v[e]; k2.v[e] = -k0.v[e] * c2.v[e]; } } }
+    const int wo = 2 * wi, ntiles = B * g.xtiles * g.ystrips;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const Up2Tile t = up2_tile(tile, g, hi, wi, xs);
+        const int jc = min(t.j, wi - 1);
+        const int64_t ob = (int64_t)t.img * 2 * hi * wo + 2 * jc;
+        const T* db = dy + ob * ldd + c;
+        T* zb = dz + ob * ldo + c;
+        const bool live_t = t.colok && cok;
+        Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c);
+        Raw8<T> dn[2][2];                                    // dy of the pair about to be consumed
+        { const int pp = min(t.ps, hi - 1);
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+              for (int col = 0; col < 2; ++col) dn[r][col].load(db + ((int64_t)(2 * pp + r) * wo + col) * ldd); }
+        up2_walk<T>(U, t.ps, t.pe, [&](int p, const float (&z)[2][2][8]) {
+            Raw8<T> d[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int col = 0; col < 2; ++col) d[r][col] = dn[r][col];
+            { const int pp = min(p + 1, hi - 1);
+#pragma unroll
+              for (int r = 0; r < 2; ++r)
+#pragma unroll
+                  for (int col = 0; col < 2; ++col) dn[r][col].load(db + ((int64_t)(2 * pp + r) * wo + col) * ldd); }
+            const bool live = live_t && p < t.pe;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int col = 0; col < 2; ++col) {
+                    F8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xh = fmaf(z[r][col][e], xs_.v[e], xo.v[e]);
+                        float gg = d[r][col].get(e);
+                        if (ACT == 1) gg *= mish_grad(fmaf(xh, gm.v[e], bt.v[e]));
+                        if (PASS2) o.v[e] = fmaf(k0.v[e], gg, fmaf(xh, k2.v[e], k1.v[e]));
+                        else if (live) { acc[0][e] += gg; acc[1][e] = fmaf(gg, xh, acc[1][e]); }
+                    }
+                    if (PASS2 && live) store8(zb + ((int64_t)(2 * p + r) * wo + col) * ldo, o);
+                }
+        });
+    }
+    if (!PASS2) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[k][e];
+            __syncthreads();
+            if (xs == 0 && cok) {
+                float* dst = partial + ((int64_t)blockIdx.x * 2 + k) * C + c;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float s = 0.f;
+                    for (int q = 0; q < g.xl; ++q) s += red[(q * g.cpb + cl) * 8 + e];
+                    dst[e] = s; }
+            }
+        }
+    }
+}
+static inline int up2_blocks(const Up2Geom& g, int B) {
+    const int64_t t = (int64_t)B * g.xtiles * g.ystrips;
+    return (int)(t < SS_COLRED_MAX_BLOCKS ? t : SS_COLRED_MAX_BLOCKS);
+}
+static inline bool up2_ok(int hi, int wi, int ho, int wo) { return ho == 2 * hi && wo == 2 * wi; }
+
+#define SS_UP_CHECK(name) \
+    SS_CHECK(B > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && (int64_t)B * ho * wo < (1LL << 31) && (int64_t)B * hi * wi * ldx < (1LL << 40), \
+             name ": bad resize geometry")
+extern "C" int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo, int C, float eps, float momentum,
+                              float* stats, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* workspace,
+                              int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(x && stats && workspace && C > 0 && C % 8 == 0 && ldx >= C && ldx % 8 == 0 && aligned16(x), "ss_bn_stats_up: bad arguments (C=%d)", C);
+    SS_UP_CHECK("ss_bn_stats_up");
+    const int64_t rows = (int64_t)B * ho * wo;
+    ColGeom g = col_geom(rows, C);
+    SS_CHECK(ws_bytes >= (int64_t)g.nb * 2 * C * 4, "ss_bn_stats_up: workspace too small");
+    int nb = g.nb;
+    if (up2_ok(hi, wi, ho, wo)) {
+        const Up2Geom u = up2_geom(B, hi, wi, C);
+        nb = up2_blocks(u, B);
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((bn_stats_up2_kernel<T>), dim3(nb, u.groups), dim3(256), 0, stream, (const T*)x, ldx, B, hi, wi, C, u, workspace));
+    } else SS_DISPATCH(dtype, {
+        BnStatUpF<T> f{(const T*)x, ldx, up_geom(hi, wi, ho, wo)};
+        hipLaunchKernelGGL((colreduce_partial_kernel<BnStatUpF<T>>), dim3(g.nb, 1), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
+    });
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, nb, C, rows, eps, momentum,
+                       stats, running_mean, running_var, num_batches_tracked, x, dtype == SS_BF16 ? 1 : 0);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
 // eval mode: stats from running buffers
 __global__ void bn_eval_stats_kernel(const float* rm, const float* rv, int C, float eps, float* stats) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -323,10 +638,12 @@ __device__ __forceinline__ int64_t bn_image_of(int64_t row, int64_t rows_per_ima
 static inline int pow2_shift(int64_t v) { return (v > 0 && (v & (v - 1)) == 0) ? __builtin_ctzll((unsigned long long)v) : -1; }
 
 // y[r] = res[r] + mask[b,c] * act(gamma * (z - mean) * rstd + beta);   act: 0 none, 1 Mish
-template <typename T, int ACT, bool MASK, bool RES>
+// UP: z is the coarse map and `up` its resize geometry (rows = B*ho*wo virtual rows, see UpGeom)
+template <typename T, int ACT, bool MASK, bool RES, bool UP = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, int64_t ldz, const float* __restrict__ stats,
         const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, int64_t ldr,
-        const float* __restrict__ mask, int64_t rows_per_image, int rpi_shift, T* __restrict__ y, int64_t ldy, int64_t rows, int C, BnWalk w) {
+        const float* __restrict__ mask, int64_t rows_per_image, int rpi_shift, T* __restrict__ y, int64_t ldy, int64_t rows, int C, BnWalk w,
+        UpGeom up) {
     const int chunks = C / 8, t = threadIdx.x, ch = t % w.cpb, rl = t / w.cpb;
     if (rl >= w.rpb) return;
     for (int cbase = 0; cbase < chunks; cbase += w.cpb) {
@@ -339,12 +656,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
           for (int e = 0; e < 8; ++e) { sc.v[e] = rs.v[e] * g.v[e]; sh.v[e] = b.v[e] - mu.v[e] * sc.v[e]; } }
         const int64_t stride = (int64_t)gridDim.x * w.rpb;
         for (int64_t r0 = (int64_t)blockIdx.x * w.rpb + rl; r0 < rows; r0 += 4 * stride) {
-            Raw8<T> v[4], q[4]; F8 m[4];
+            Raw8<T> v[4], q[4]; F8 m[4]; UpTaps<T> ut[UP ? 4 : 1];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int64_t r = r0 + j * stride;
                 if (r < rows) {
-                    v[j].load(z + r * ldz + c);
+                    if (UP) up_issue<T>(z, ldz, up, r, c, ut[UP ? j : 0]); else v[j].load(z + r * ldz + c);
                     if (RES) q[j].load(res + r * ldr + c);
                     if (MASK) m[j] = load8(mask + bn_image_of(r, rows_per_image, rpi_shift) * C + c);
                 }
@@ -356,7 +673,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
                     F8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float u = fmaf(v[j].get(e), sc.v[e], sh.v[e]);
+                        float u = fmaf(UP ? up_value<T>(ut[UP ? j : 0], e) : v[j].get(e), sc.v[e], sh.v[e]);
                         if (ACT == 1) u = mish_f(u);
                         if (MASK) u *= m[j].v[e];
                         if (RES) u += q[j].get(e);
@@ -385,7 +702,7 @@ extern "C" int ss_bn_apply(int dtype, const void* z, int64_t ldz, const float* s
     BnWalk w{g.cpb, g.rpb};
     const int blocks = bn_walk_blocks(rows, g.rpb), sh = pow2_shift(rows_per_image);
 #define SS_BN_APPLY(ACT, MASK, RES) hipLaunchKernelGGL((bn_apply_kernel<T, ACT, MASK, RES>), dim3(blocks), dim3(256), 0, stream, (const T*)z, ldz, \
-        stats, gamma, beta, (const T*)res, ldr, mask, rows_per_image, sh, (T*)y, ldy, rows, C, w)
+        stats, gamma, beta, (const T*)res, ldr, mask, rows_per_image, sh, (T*)y, ldy, rows, C, w, UpGeom{})
     SS_DISPATCH(dtype, {
         if (act) { if (mask) { if (res) SS_BN_APPLY(1, true, true); else SS_BN_APPLY(1, true, false); }
                    else { if (res) SS_BN_APPLY(1, false, true); else SS_BN_APPLY(1, false, false); } }
@@ -397,15 +714,41 @@ extern "C" int ss_bn_apply(int dtype, const void* z, int64_t ldz, const float* s
     return 0;
 }
 
+extern "C" int ss_bn_apply_up(int dtype, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo, const float* stats,
+                              const float* gamma, const float* beta, void* y, int64_t ldy, int C, int act, hipStream_t stream) {
+    SS_CHECK(x && stats && gamma && beta && y && C > 0 && C % 8 == 0 && aligned16(x) && aligned16(y), "ss_bn_apply_up: bad arguments (C=%d)", C);
+    SS_CHECK(ldx >= C && ldy >= C && ldx % 8 == 0 && ldy % 8 == 0, "ss_bn_apply_up: bad leading dimensions");
+    SS_CHECK(act == 0 || act == 1, "ss_bn_apply_up: act must be 0 (none) or 1 (Mish)");
+    SS_UP_CHECK("ss_bn_apply_up");
+    const int64_t rows = (int64_t)B * ho * wo;
+    ColGeom g = col_geom(rows, C);
+    BnWalk w{g.cpb, g.rpb};
+    const int blocks = bn_walk_blocks(rows, g.rpb);
+    const UpGeom up = up_geom(hi, wi, ho, wo);
+#define SS_BN_APPLY_UP(ACT) hipLaunchKernelGGL((bn_apply_kernel<T, ACT, false, false, true>), dim3(blocks), dim3(256), 0, stream, (const T*)x, ldx, \
+        stats, gamma, beta, (const T*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, -1, (T*)y, ldy, rows, C, w, up)
+    if (up2_ok(hi, wi, ho, wo)) {
+        const Up2Geom u = up2_geom(B, hi, wi, C);
+        dim3 grid((unsigned)(B * u.xtiles * u.ystrips), (unsigned)u.groups);
+        SS_DISPATCH(dtype, {
+            if (act) hipLaunchKernelGGL((bn_apply_up2_kernel<T, 1>), grid, dim3(256), 0, stream, (const T*)x, ldx, hi, wi, stats, gamma, beta, (T*)y, ldy, C, u);
+            else hipLaunchKernelGGL((bn_apply_up2_kernel<T, 0>), grid, dim3(256), 0, stream, (const T*)x, ldx, hi, wi, stats, gamma, beta, (T*)y, ldy, C, u);
+        });
+    } else SS_DISPATCH(dtype, { if (act) SS_BN_APPLY_UP(1); else SS_BN_APPLY_UP(0); });
+#undef SS_BN_APPLY_UP
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
 // backward.  g = dy * mask * act'(u), u = xhat * gamma + beta.
 //   pass 1: partial[b][0][c] = sum g, partial[b][1][c] = sum g * xhat over the rows of workgroup b (fixed order)
 //   pass 2: dz = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat))
 // PASS2 selects which; both recompute g from dy and z (10 bytes per element in total, nothing extra stored by the forward).
-template <typename T, int ACT, bool MASK, bool PASS2>
+template <typename T, int ACT, bool MASK, bool PASS2, bool UP = false>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const T* __restrict__ dy, int64_t ldd, const T* __restrict__ z, int64_t ldz,
         const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
         int64_t rows_per_image, int rpi_shift, const float* __restrict__ coef, T* __restrict__ dz, int64_t ldo,
-        float* __restrict__ partial, int64_t rows, int C, BnWalk w) {
+        float* __restrict__ partial, int64_t rows, int C, BnWalk w, UpGeom up) {
     __shared__ float red[PASS2 ? 1 : 256 * 8];
     const int chunks = C / 8, t = threadIdx.x, ch = t % w.cpb, rl = t / w.cpb;
     const bool rowlane = rl < w.rpb;
@@ -426,12 +769,13 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const T* __restrict__ dy, i
                   for (int e = 0; e < 8; ++e) { k0.v[e] = gm.v[e] * rs.v[e]; k1.v[e] = -k0.v[e] * c1.v[e]; k2.v[e] = -k0.v[e] * c2.v[e]; } } }
             const int64_t stride = (int64_t)gridDim.x * w.rpb;
             for (int64_t r0 = (int64_t)blockIdx.x * w.rpb + rl; r0 < rows; r0 += 4 * stride) {
-                Raw8<T> d[4], v[4]; F8 m[4];
+                Raw8<T> d[4], v[4]; F8 m[4]; UpTaps<T> ut[UP ? 4 : 1];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int64_t r = r0 + j * stride;
                     if (r < rows) {
-                        d[j].load(dy + r * ldd + c); v[j].load(z + r * ldz + c);
+                        d[j].load(dy + r * ldd + c);
+                        if (UP) up_issue<T>(z, ldz, up, r, c, ut[UP ? j : 0]); else v[j].load(z + r * ldz + c);
                         if (MASK) m[j] = load8(mask + bn_image_of(r, rows_per_image, rpi_shift) * C + c);
                     }
                 }
@@ -442,7 +786,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const T* __restrict__ dy, i
                         F8 o;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float xh = fmaf(v[j].get(e), xs.v[e], xo.v[e]);
+                            const float xh = fmaf(UP ? up_value<T>(ut[UP ? j : 0], e) : v[j].get(e), xs.v[e], xo.v[e]);
                             float gg = d[j].get(e);
                             if (MASK) gg *= m[j].v[e];
                             if (ACT == 1) gg *= mish_grad(fmaf(xh, gm.v[e], bt.v[e]));
@@ -510,7 +854,7 @@ extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, 
     BnWalk w{g.cpb, g.rpb};
     const int blocks2 = bn_walk_blocks(rows, g.rpb), sh = pow2_shift(rows_per_image);
 #define SS_BN_BWD(ACT, MASK, P2, GRID) hipLaunchKernelGGL((bn_bwd_kernel<T, ACT, MASK, P2>), dim3(GRID), dim3(256), 0, stream, (const T*)dy, ldd, \
-        (const T*)z, ldz, stats, gamma, beta, mask, rows_per_image, sh, coef, (T*)dz, ldo, workspace, rows, C, w)
+        (const T*)z, ldz, stats, gamma, beta, mask, rows_per_image, sh, coef, (T*)dz, ldo, workspace, rows, C, w, UpGeom{})
 #define SS_BN_BWD_PASS(P2, GRID) do { \
         if (act) { if (mask) SS_BN_BWD(1, true, P2, GRID); else SS_BN_BWD(1, false, P2, GRID); } \
         else { if (mask) SS_BN_BWD(0, true, P2, GRID); else SS_BN_BWD(0, false, P2, GRID); } } while (0)
@@ -523,6 +867,53 @@ extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, 
     });
 #undef SS_BN_BWD_PASS
 #undef SS_BN_BWD
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same with z = resize(x) read through its taps (no mask): dz is the gradient of the RESIZED map, [B*ho*wo, C]
+extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo,
+                            const float* stats, const float* gamma, const float* beta, int training, void* dz, int64_t ldo,
+                            float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(dy && x && stats && gamma && beta && dz && dgamma_dbeta && workspace && C > 0 && C % 8 == 0, "ss_bn_bwd_up: bad arguments");
+    SS_CHECK(ldd >= C && ldx >= C && ldo >= C && ldd % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && aligned16(dy) && aligned16(x) && aligned16(dz),
+             "ss_bn_bwd_up: bad leading dimensions");
+    SS_CHECK(act == 0 || act == 1, "ss_bn_bwd_up: act must be 0 (none) or 1 (Mish)");
+    SS_UP_CHECK("ss_bn_bwd_up");
+    const int64_t rows = (int64_t)B * ho * wo;
+    ColGeom g = col_geom(rows, C);
+    SS_CHECK(ws_bytes >= ((int64_t)g.nb * 2 * C + 2 * C) * 4, "ss_bn_bwd_up: workspace too small");
+    float* coef = workspace + (int64_t)g.nb * 2 * C;
+    BnWalk w{g.cpb, g.rpb};
+    const int blocks2 = bn_walk_blocks(rows, g.rpb);
+    const UpGeom up = up_geom(hi, wi, ho, wo);
+#define SS_BN_BWD_UP(ACT, P2, GRID) hipLaunchKernelGGL((bn_bwd_kernel<T, ACT, false, P2, true>), dim3(GRID), dim3(256), 0, stream, (const T*)dy, ldd, \
+        (const T*)x, ldx, stats, gamma, beta, (const float*)nullptr, (int64_t)0, -1, coef, (T*)dz, ldo, workspace, rows, C, w, up)
+    if (up2_ok(hi, wi, ho, wo)) {
+        const Up2Geom u = up2_geom(B, hi, wi, C);
+        const int nb = up2_blocks(u, B);
+        dim3 g1((unsigned)nb, (unsigned)u.groups), g2((unsigned)(B * u.xtiles * u.ystrips), (unsigned)u.groups);
+#define SS_BN_BWD_UP2(ACT, P2, GRID) hipLaunchKernelGGL((bn_bwd_up2_kernel<T, ACT, P2>), GRID, dim3(256), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, \
+        B, hi, wi, stats, gamma, beta, coef, (T*)dz, ldo, workspace, C, u)
+        SS_DISPATCH(dtype, {
+            if (act) SS_BN_BWD_UP2(1, false, g1); else SS_BN_BWD_UP2(0, false, g1);
+            SS_LAUNCH_CHECK();
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, nb, C, rows, training, dgamma_dbeta, coef);
+            SS_LAUNCH_CHECK();
+            if (act) SS_BN_BWD_UP2(1, true, g2); else SS_BN_BWD_UP2(0, true, g2);
+        });
+#undef SS_BN_BWD_UP2
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
+    SS_DISPATCH(dtype, {
+        if (act) SS_BN_BWD_UP(1, false, g.nb); else SS_BN_BWD_UP(0, false, g.nb);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, g.nb, C, rows, training, dgamma_dbeta, coef);
+        SS_LAUNCH_CHECK();
+        if (act) SS_BN_BWD_UP(1, true, blocks2); else SS_BN_BWD_UP(0, true, blocks2);
+    });
+#undef SS_BN_BWD_UP
     SS_LAUNCH_CHECK();
     return 0;
 }

@@ -3,6 +3,7 @@
 // slices of concat buffers (K10), NCHW image -> NHWC, weight packing / casting, small elementwise helpers.
 // All bandwidth-bound: 16-byte channel-contiguous accesses wherever C % 8 == 0, scalar fall-backs for C = 3 / 6.
 #include "common.h"
+#include "bilinear.h"
 
 // ------------------------------------------------------------------ im2col / col2im   (column order: ky, kx, c)
 // grid: (B*ho output rows, blocks over the wo * k*k * C/8 chunk items of a row)
@@ -137,23 +138,6 @@ extern "C" int ss_col2im(int dtype, const void* col, void* dx, int B, int H, int
 }
 
 // ------------------------------------------------------------------ bilinear (align_corners = False), torch semantics
-struct LinTap { int i0, i1; float l0, l1; };
-__device__ __forceinline__ LinTap lin_tap(int o, float scale, int in) {
-    float src = scale * (o + 0.5f) - 0.5f;
-    if (src < 0.f) src = 0.f;
-    LinTap t; t.i0 = (int)src; if (t.i0 > in - 1) t.i0 = in - 1;
-    t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
-    t.l1 = src - t.i0; t.l0 = 1.f - t.l1;
-    return t;
-}
-
-// One interpolated value, with the roundings spelled out (explicit fma) so that every kernel below that interpolates -- the
-// resize kernels and the fused resize + arg-max of the prediction writer -- produces the same bits from the same taps.
-__device__ __forceinline__ float bilerp(const LinTap& ty, const LinTap& tx, float a, float b, float c, float d) {
-    const float top = fmaf(tx.l1, b, tx.l0 * a), bot = fmaf(tx.l1, d, tx.l0 * c);
-    return fmaf(ty.l1, bot, ty.l0 * top);
-}
-
 // grid: (B*ho output rows, blocks over the wo * chunks items of a row); the vertical tap is uniform per workgroup
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,

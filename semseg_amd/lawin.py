@@ -127,18 +127,22 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     S.update(gp=gp, zp=zp, stp=stp)
 
     # cat: 1x1 conv at S/8, bilinear x2, BN + Mish at S/4; low-level fuse; classifier
+    # (the S/4 map z4 = resize(z8) is never written: the BatchNorm kernels read it through its bilinear taps, ss_bn_*_up)
     z8 = ops.gemm_nt(cat5, _conv_w(P['cat.conv.weight'], T))
-    z4 = ops.bilinear_fwd(z8, B, H8, W8, H4, W4)
-    stc = _bn_stats(z4, P, Bf, 'cat.bn', training)
+    if training:
+        stc = ops.bn_stats_up(z8, B, H8, W8, H4, W4, 1e-5, 0.1, Bf['cat.bn.running_mean'], Bf['cat.bn.running_var'],
+                              Bf['cat.bn.num_batches_tracked'])
+    else:
+        stc = ops.bn_eval_stats(Bf['cat.bn.running_mean'], Bf['cat.bn.running_var'])
     cat2 = torch.empty((R4, E + 48), dtype=T, device=dev)
-    ops.bn_apply(z4, stc, P['cat.bn.weight'], P['cat.bn.bias'], act=1, out=cat2[:, :E])
+    ops.bn_apply_up(z8, B, H8, W8, H4, W4, stc, P['cat.bn.weight'], P['cat.bn.bias'], act=1, out=cat2[:, :E])
     ops.gemm_nt(t[0], w_fwd(P['linear_c1.proj.weight'], T), bias=P['linear_c1.proj.bias'], out=cat2[:, E:])
     zl = ops.gemm_nt(cat2, _conv_w(P['low_level_fuse.conv.weight'], T))
     stl = _bn_stats(zl, P, Bf, 'low_level_fuse.bn', training)
     fused = ops.bn_apply(zl, stl, P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'], act=1, mask=drop_mask,
                          rows_per_image=H4 * W4 if drop_mask is not None else 0)
     seg = ops.gemm_nt(fused, _conv_w(P['linear_pred.weight'], T), bias=P['linear_pred.bias'])
-    S.update(z4=z4, stc=stc, cat2=cat2, zl=zl, stl=stl, fused=fused, drop_mask=drop_mask, training=training)
+    S.update(z8=z8, stc=stc, cat2=cat2, zl=zl, stl=stl, fused=fused, drop_mask=drop_mask, training=training)
     return seg, S
 
 
@@ -166,7 +170,7 @@ def head_backward(P, S, dseg, E):
     G['linear_c1.proj.weight'], G['linear_c1.proj.bias'] = ops.gemm_tn(dc1, t[0], colsum=True)
     dt = [ops.gemm_nt(dc1, w_bwd(P['linear_c1.proj.weight'], T)), None, None, None]
     # cat
-    dz4, dgb = ops.bn_bwd(dcat2[:, :E], S['z4'], S['stc'], P['cat.bn.weight'], P['cat.bn.bias'], act=1, training=training)
+    dz4, dgb = ops.bn_bwd_up(dcat2[:, :E], S['z8'], B, H8, W8, H4, W4, S['stc'], P['cat.bn.weight'], P['cat.bn.bias'], act=1, training=training)
     bn_grads('cat.bn', dgb)
     dz8 = ops.bilinear_bwd(dz4, B, H8, W8, H4, W4)
     G['cat.conv.weight'] = ops.gemm_tn(dz8, S['cat5'])

@@ -430,6 +430,62 @@ def bilinear_bwd(dy, B, hi, wi, ho, wo, out=None, accumulate=False):
     return out
 
 
+# ------------------------------------------------------------------ BatchNorm of a bilinear resize (the resized tensor never exists)
+def _up_args(x, B, hi, wi, name):
+    rows, C, ldx = _mat(x, 'x')
+    if rows != B * hi * wi or C % 8:
+        raise ValueError(f'{name}: x must be [B*hi*wi, C] with C % 8 == 0')
+    return C, ldx
+
+
+def bn_stats_up(x, B, hi, wi, ho, wo, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt=None):
+    """bn_stats(bilinear_fwd(x, B, hi, wi, ho, wo)) without the resized tensor -> stats [2,C]."""
+    dev = _dev(x)
+    C, ldx = _up_args(x, B, hi, wi, 'bn_stats_up')
+    _f32(running_mean, 'running_mean', C), _f32(running_var, 'running_var', C)
+    if nbt is not None and nbt.dtype != torch.int64:
+        raise ValueError('bn_stats_up: num_batches_tracked must be int64')
+    stats = torch.empty((2, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, COLRED_BLOCKS * 2 * C * 4)
+    check(lib().ss_bn_stats_up(dt(x), _p(x), ldx, B, hi, wi, ho, wo, C, eps, momentum, _p(stats), _p(running_mean), _p(running_var), _p(nbt),
+                               _p(ws), ws.numel(), _stream()))
+    return stats
+
+
+def bn_apply_up(x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, out=None):
+    """bn_apply(bilinear_fwd(x, ...), stats, gamma, beta, act) -> [B*ho*wo, C] (may be a channel slice of a wider buffer)."""
+    dev = _dev(x)
+    C, ldx = _up_args(x, B, hi, wi, 'bn_apply_up')
+    _f32(stats, 'stats', 2 * C), _f32(gamma, 'gamma', C), _f32(beta, 'beta', C)
+    if out is None:
+        out = torch.empty((B * ho * wo, C), dtype=x.dtype, device=dev)
+    ro, Co, ldy = _mat(out, 'out')
+    if (ro, Co) != (B * ho * wo, C) or out.dtype != x.dtype:
+        raise ValueError('bn_apply_up: bad out')
+    check(lib().ss_bn_apply_up(dt(x), _p(x), ldx, B, hi, wi, ho, wo, _p(stats), _p(gamma), _p(beta), _p(out), ldy, C, act, _stream()))
+    return out
+
+
+def bn_bwd_up(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True, out=None):
+    """bn_bwd(dy, bilinear_fwd(x, ...), ...) -> dz [B*ho*wo, C] (gradient of the RESIZED map), dgb [2,C]."""
+    dev = _dev(x)
+    C, ldx = _up_args(x, B, hi, wi, 'bn_bwd_up')
+    rd, Cd, ldd = _mat(dy, 'dy')
+    if (rd, Cd) != (B * ho * wo, C) or dy.dtype != x.dtype:
+        raise ValueError('bn_bwd_up: dy mismatch')
+    _f32(stats, 'stats', 2 * C), _f32(gamma, 'gamma', C), _f32(beta, 'beta', C)
+    if out is None:
+        out = torch.empty((B * ho * wo, C), dtype=x.dtype, device=dev)
+    ro, Co, ldo = _mat(out, 'out')
+    if (ro, Co) != (B * ho * wo, C) or out.dtype != x.dtype:
+        raise ValueError('bn_bwd_up: bad out')
+    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, (COLRED_BLOCKS * 2 * C + 2 * C) * 4)
+    check(lib().ss_bn_bwd_up(dt(x), _p(dy), ldd, _p(x), ldx, B, hi, wi, ho, wo, _p(stats), _p(gamma), _p(beta), int(training),
+                             _p(out), ldo, _p(dgb), C, act, _p(ws), ws.numel(), _stream()))
+    return out, dgb
+
+
 # ------------------------------------------------------------------ casts / packing / elementwise
 def cast(x, dtype):
     _dev(x)

@@ -192,6 +192,55 @@ def test_batchnorm(ops, dtype, rows, C, act):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,hi,wi,ho,wo,C,act', [(2, 8, 8, 16, 16, 64, 1), (1, 5, 7, 10, 14, 128, 0), (3, 6, 4, 13, 9, 48, 1), (2, 16, 16, 32, 32, 512, 1),
+                                                 (1, 1, 3, 2, 6, 16, 0), (2, 50, 3, 100, 6, 1032, 1)])
+def test_batchnorm_of_bilinear_resize(ops, dtype, B, hi, wi, ho, wo, C, act):
+    """ss_bn_stats_up / ss_bn_apply_up / ss_bn_bwd_up (LawinHead `cat`: BatchNorm + Mish of a bilinear resize, modules/lawin.py:213-222,
+    101-105) against F.interpolate + F.batch_norm (+ F.mish) in fp32, and bit for bit against the unfused pair ss_bilinear_fwd +
+    ss_bn_stats / ss_bn_apply / ss_bn_bwd that they replace."""
+    x = rnd(B * hi * wi, C, scale=1.5) + 0.3
+    g, b, dy = 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2), rnd(B * ho * wo, C, seed=3)
+    rm, rv = 0.1 * rnd(C, seed=5), 1 + 0.1 * rnd(C, seed=6).abs()
+    xd, dyd = dev(x, dtype), dev(dy, dtype)
+    # the unfused pair
+    z = ops.bilinear_fwd(xd, B, hi, wi, ho, wo)
+    rm1, rv1, n1 = dev(rm), dev(rv), torch.zeros((), dtype=torch.int64, device='cuda')
+    st1 = ops.bn_stats(z, 1e-5, 0.1, rm1, rv1, n1)
+    y1 = ops.bn_apply(z, st1, dev(g), dev(b), act)
+    dz1, dgb1 = ops.bn_bwd(dyd, z, st1, dev(g), dev(b), act)
+    # fused: writes into a channel slice of a wider buffer, as the head does
+    rm2, rv2, n2 = dev(rm), dev(rv), torch.zeros((), dtype=torch.int64, device='cuda')
+    st2 = ops.bn_stats_up(xd, B, hi, wi, ho, wo, 1e-5, 0.1, rm2, rv2, n2)
+    # statistics: the same values summed in another order (the x2 case walks image columns, not matrix rows)
+    assert rel(st2, st1) < 1e-5 and rel(rm2, rm1) < 1e-5 and rel(rv2, rv1) < 1e-5 and int(n2) == 1
+    wide = torch.full((B * ho * wo, C + 16), 7.0, dtype=dtype, device='cuda')
+    ops.bn_apply_up(xd, B, hi, wi, ho, wo, st1, dev(g), dev(b), act, out=wide[:, 8:8 + C])
+    assert torch.equal(y1, wide[:, 8:8 + C])                  # same statistics in -> the same bits out
+    assert float((wide[:, :8] - 7).abs().max()) == 0 and float((wide[:, 8 + C:] - 7).abs().max()) == 0
+    dz2, dgb2 = ops.bn_bwd_up(dyd, xd, B, hi, wi, ho, wo, st1, dev(g), dev(b), act)
+    assert rel(dgb2, dgb1) < 1e-5 and rel(dz2, dz1) < (1e-5 if dtype == torch.float32 else 4e-3)
+    # torch fp32 on the values the kernel sees; the resized map is rounded to the storage dtype as the reference's autocast output is
+    xr = q(x, dtype).requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    zi = F.interpolate(xr.view(B, hi, wi, C).permute(0, 3, 1, 2), size=(ho, wo), mode='bilinear', align_corners=False)
+    zq = zi + (zi.detach().to(dtype).float() - zi.detach())
+    u = F.batch_norm(zq, rm.clone(), rv.clone(), gr, br, True, 0.1, 1e-5)
+    ref = (F.mish(u) if act else u).permute(0, 2, 3, 1).reshape(B * ho * wo, C)
+    ref.backward(q(dy, dtype))
+    assert rel(wide[:, 8:8 + C], ref) < _tol(dtype)
+    assert rel(dgb2[0], gr.grad) < (1e-4 if dtype == torch.float32 else 2e-3) and rel(dgb2[1], br.grad) < (1e-4 if dtype == torch.float32 else 2e-3)
+    dx = ops.bilinear_bwd(dz2, B, hi, wi, ho, wo)
+    assert rel(dx, xr.grad) < _gtol(dtype)
+    # eval mode
+    st3 = ops.bn_eval_stats(dev(rm), dev(rv))
+    y3 = ops.bn_apply_up(xd, B, hi, wi, ho, wo, st3, dev(g), dev(b), act)
+    assert torch.equal(y3, ops.bn_apply(z, st3, dev(g), dev(b), act))
+    dz3, dgb3 = ops.bn_bwd_up(dyd, xd, B, hi, wi, ho, wo, st3, dev(g), dev(b), act, training=False)
+    dz4, dgb4 = ops.bn_bwd(dyd, z, st3, dev(g), dev(b), act, training=False)
+    assert torch.equal(dz3, dz4) and rel(dgb3, dgb4) < 1e-5   # eval mode: dz does not depend on the sums
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_colsum(ops, dtype):
     x = rnd(3 * 500, 64)
     out = ops.colsum(dev(x, dtype), groups=3, scale=0.5)
