@@ -106,6 +106,19 @@ int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* x, int64_t 
                  const float* stats, const float* gamma, const float* beta, int training, void* dz, int64_t ldo,
                  float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
+/* LawinHead's tail seg = linear_pred(dropout(low_level_fuse's Mish(BatchNorm(z)))) (modules/lawin.py:101-105,227-228) without the
+ * E-channel activation in memory.  wp [nc, C] / bp [nc] are the classifier's fp32 parameters (nc <= 8; C = 8 * a power of two,
+ * <= 512); seg and dseg are [rows, nc] in the compute dtype.  ss_bn_bwd_classify returns dz, [2,C] (dgamma, dbeta) and the
+ * classifier's weight gradient dwp [nc, C] fp32 (its bias gradient is the column sum of dseg: ss_colsum_small);
+ * workspace >= (1024*(2+nc)*C + 2*C) floats. */
+int ss_bn_apply_classify(int dtype, const void* z, int64_t ldz, const float* stats, const float* gamma, const float* beta,
+                         const float* mask, int64_t rows_per_image, const float* wp, const float* bp, int nc, void* seg,
+                         int64_t lds_, int64_t rows, int C, hipStream_t stream);
+int ss_bn_bwd_classify(int dtype, const void* dseg, int64_t ldd, const void* z, int64_t ldz, const float* stats, const float* gamma,
+                       const float* beta, const float* mask, int64_t rows_per_image, int training, const float* wp, int nc, void* dz,
+                       int64_t ldo, float* dgamma_dbeta, float* dwp, int64_t rows, int C, float* workspace, int64_t ws_bytes,
+                       hipStream_t stream);
+
 /* ---- Mix-FFN depthwise 3x3 (+bias, +GELU) on token layout (modules/segformer.py:44-53,64).
  * w9c: weights repacked tap-major [9][C] fp32.  act: 0 none, 1 GELU(erf).
  * bwd: g = dy*act'(dw(x)+b) (written), dw_db = [10][C] fp32 (9 taps + bias); dx = ss_dwconv3_fwd(g, flipped taps). */

@@ -918,6 +918,305 @@ extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* 
     return 0;
 }
 
+// ------------------------------------------------------------------ BatchNorm + Mish + Dropout2d + the nc-class 1x1 classifier in one pass
+// LawinHead's tail (modules/lawin.py:227-228): seg = linear_pred(dropout(Mish(BN(zl)))).  The E-channel activation between the
+// BatchNorm and the classifier is a full-resolution tensor that is written once and read twice (classifier forward, its weight
+// gradient) and whose gradient is written once and read twice (both passes of the BatchNorm backward).  Here it never exists:
+//   forward : a pixel's E channels sit in the cpb <= 64 lanes of one wave (8 channels per lane); every lane forms its share of the
+//             NC dot products with the classifier rows it keeps in registers, the lanes are summed and one lane stores the logits;
+//   backward: d(activation) = dseg . Wp is 6 fmas per element from the pixel's NC logit gradients (a broadcast load) instead of
+//             a 2-byte read; pass 1 also accumulates the classifier's weight gradient from the recomputed activation.
+// Mish and its derivative share one exp and their reciprocals.
+__device__ __forceinline__ void mish_both(float x, float& val, float& grad) {
+    const float e = __expf(fminf(x, 20.f)), n = e * (e + 2.f), d = __builtin_amdgcn_rcpf(n + 2.f);
+    const float t = n * d, omt2 = 4.f * (n + 1.f) * d * d;
+    val = x * t;
+    grad = t + x * omt2 * (e * __builtin_amdgcn_rcpf(1.f + e));
+}
+template <typename T> __device__ __forceinline__ void load_row_nc(const T* p, int nc, float (&o)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = k < nc ? to_f(p[k]) : 0.f;
+}
+
+template <typename T, int NC, bool MASK>
+__global__ __launch_bounds__(256) void bn_apply_cls_kernel(const T* __restrict__ z, int64_t ldz, const float* __restrict__ stats,
+        const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask, int64_t rows_per_image, int rpi_shift,
+        const float* __restrict__ wp, const float* __restrict__ bp, T* __restrict__ seg, int64_t lds_, int64_t rows, int C, BnWalk w) {
+    const int t = threadIdx.x, ch = t % w.cpb, rl = t / w.cpb, c = ch * 8;
+    F8 sc, sh; float wk[NC][8];
+    { F8 mu = load8(stats + c), rs = load8(stats + C + c), g = load8(gamma + c), b = load8(beta + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc.v[e] = rs.v[e] * g.v[e]; sh.v[e] = b.v[e] - mu.v[e] * sc.v[e]; } }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { F8 r = load8(wp + (int64_t)k * C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wk[k][e] = r.v[e]; }
+    const int64_t stride = (int64_t)gridDim.x * w.rpb;
+    for (int64_t r0 = (int64_t)blockIdx.x * w.rpb + rl; r0 < rows; r0 += 4 * stride) {      // all lanes of a wave share r0 (cpb divides 64)
+        Raw8<T> v[4]; F8 m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = r0 + j * stride;
+            if (r < rows) {
+                v[j].load(z + r * ldz + c);
+                if (MASK) m[j] = load8(mask + bn_image_of(r, rows_per_image, rpi_shift) * C + c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = r0 + j * stride;
+            if (r < rows) {
+                float dot[NC];
+#pragma unroll
+                for (int k = 0; k < NC; ++k) dot[k] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float u = mish_f(fmaf(v[j].get(e), sc.v[e], sh.v[e]));
+                    if (MASK) u *= m[j].v[e];
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) dot[k] = fmaf(u, wk[k][e], dot[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < NC; ++k) dot[k] = group_sum(dot[k], w.cpb);
+                if (ch == 0) {
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) seg[r * lds_ + k] = from_f<T>(dot[k] + bp[k]);
+                }
+            }
+        }
+    }
+}
+
+// PASS2 = false: partial[b][0][c] = sum g, [1] = sum g * xhat, partial2[b][k][c] = sum dseg[k] * activation[c]; true: dz
+template <typename T, int NC, bool MASK, bool PASS2>
+__global__ __launch_bounds__(256) void bn_bwd_cls_kernel(const T* __restrict__ dseg, int64_t ldd, const T* __restrict__ z, int64_t ldz,
+        const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
+        int64_t rows_per_image, int rpi_shift, const float* __restrict__ wp, const float* __restrict__ coef, T* __restrict__ dz, int64_t ldo,
+        float* __restrict__ partial, float* __restrict__ partial2, int64_t rows, int C, BnWalk w) {
+    constexpr int RF = 2;                                  // rows in flight (the accumulators and classifier rows take the registers)
+    __shared__ float red[PASS2 ? 1 : 256 * 8];
+    const int t = threadIdx.x, ch = t % w.cpb, rl = t / w.cpb, c = ch * 8;
+    float acc[2][8], aw[PASS2 ? 1 : NC][8], wk[NC][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    if (!PASS2) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) aw[k][e] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { F8 r = load8(wp + (int64_t)k * C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wk[k][e] = r.v[e]; }
+    F8 xs, xo, gm, bt, k0, k1, k2;                         // xhat = z * xs + xo;  dz = k0 * g + k1 + xhat * k2
+    { F8 mu = load8(stats + c), rs = load8(stats + C + c);
+      gm = load8(gamma + c); bt = load8(beta + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xs.v[e] = rs.v[e]; xo.v[e] = -mu.v[e] * rs.v[e]; }
+      if (PASS2) { F8 c1 = load8(coef + c), c2 = load8(coef + C + c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { k0.v[e] = gm.v[e] * rs.v[e]; k1.v[e] = -k0.v[e] * c1.v[e]; k2.v[e] = -k0.v[e] * c2.v[e]; } } }
+    const int64_t stride = (int64_t)gridDim.x * w.rpb;
+    for (int64_t r0 = (int64_t)blockIdx.x * w.rpb + rl; r0 < rows; r0 += RF * stride) {
+        Raw8<T> v[RF]; F8 m[RF]; float ds[RF][8];
+#pragma unroll
+        for (int j = 0; j < RF; ++j) {
+            const int64_t r = r0 + j * stride;
+            if (r < rows) {
+                v[j].load(z + r * ldz + c);
+                load_row_nc<T>(dseg + r * ldd, NC, ds[j]);
+                if (MASK) m[j] = load8(mask + bn_image_of(r, rows_per_image, rpi_shift) * C + c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RF; ++j) {
+            const int64_t r = r0 + j * stride;
+            if (r < rows) {
+                F8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = fmaf(v[j].get(e), xs.v[e], xo.v[e]);
+                    float val, grd;
+                    mish_both(fmaf(xh, gm.v[e], bt.v[e]), val, grd);
+                    float gg = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) gg = fmaf(ds[j][k], wk[k][e], gg);
+                    if (MASK) { gg *= m[j].v[e]; val *= m[j].v[e]; }
+                    gg *= grd;
+                    if (PASS2) o.v[e] = fmaf(k0.v[e], gg, fmaf(xh, k2.v[e], k1.v[e]));
+                    else {
+                        acc[0][e] += gg; acc[1][e] = fmaf(gg, xh, acc[1][e]);
+#pragma unroll
+                        for (int k = 0; k < NC; ++k) aw[k][e] = fmaf(ds[j][k], val, aw[k][e]);
+                    }
+                }
+                if (PASS2) store8(dz + r * ldo + c, o);
+            }
+        }
+    }
+    if (!PASS2) {
+#pragma unroll
+        for (int k = 0; k < 2 + NC; ++k) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[t * 8 + e] = k < 2 ? acc[k < 2 ? k : 0][e] : aw[k < 2 ? 0 : k - 2][e];
+            __syncthreads();
+            if (rl == 0) {
+                float* dst = k < 2 ? partial + ((int64_t)blockIdx.x * 2 + k) * C + c : partial2 + ((int64_t)blockIdx.x * NC + (k - 2)) * C + c;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float s = 0.f;
+                    for (int j = 0; j < w.rpb; ++j) s += red[(j * w.cpb + ch) * 8 + e];
+                    dst[e] = s;
+                }
+            }
+        }
+    }
+}
+
+// bf16 forward on the matrix cores: a wave owns 16 pixels at a time; its lanes (8 channels of one pixel each) leave the activation
+// in a wave-private LDS tile [16][C], the tile is read back as v_mfma_f32_16x16x32_bf16 A fragments (lane = pixel, 8 consecutive
+// channels) against the classifier rows held as B fragments in registers (classes >= NC are zero columns), and the lanes of the
+// first NC columns store the logits.  Operands are bf16 with fp32 accumulation, which is what the reference's autocast conv does.
+template <int NC, bool MASK, int CPB>
+__global__ __launch_bounds__(256) void bn_apply_cls_mfma_kernel(const bf16* __restrict__ z, int64_t ldz, const float* __restrict__ stats,
+        const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask, int64_t rows_per_image, int rpi_shift,
+        const float* __restrict__ wp, const float* __restrict__ bp, bf16* __restrict__ seg, int64_t lds_, int64_t rows) {
+    constexpr int C = CPB * 8, PITCH = C * 2 + 16, RPS = 64 / CPB, KS = C / 32 > 0 ? C / 32 : 1;      // RPS pixels per wave step
+    __shared__ __attribute__((aligned(16))) char tile[4][16 * PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ch = lane % CPB, pr = lane / CPB, c = ch * 8;
+    char* tl = tile[wave];
+    F8 sc, sh;
+    { F8 mu = load8(stats + c), rs = load8(stats + C + c), g = load8(gamma + c), b = load8(beta + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc.v[e] = rs.v[e] * g.v[e]; sh.v[e] = b.v[e] - mu.v[e] * sc.v[e]; } }
+    const int col = lane & 15, kg = lane >> 4;
+    bf16x8 wf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int k = 32 * s + 8 * kg + e; wf[s][e] = (col < NC && k < C) ? (bf16)wp[(int64_t)col * C + k] : (bf16)0.f; }
+    }
+    const float bias = col < NC ? bp[col] : 0.f;
+    const int64_t ntile = (rows + 15) / 16;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntile; t += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = t * 16;
+        bf16x8 v[16 / RPS];
+#pragma unroll
+        for (int i = 0; i < 16 / RPS; ++i) {
+            const int64_t r = min(r0 + i * RPS + pr, rows - 1);
+            v[i] = *(const bf16x8*)(z + r * ldz + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 16 / RPS; ++i) {
+            const int64_t r = min(r0 + i * RPS + pr, rows - 1);
+            F8 m;
+            if (MASK) m = load8(mask + bn_image_of(r, rows_per_image, rpi_shift) * C + c);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float u = mish_f(fmaf((float)v[i][e], sc.v[e], sh.v[e]));
+                if (MASK) u *= m.v[e];
+                o[e] = (bf16)u;
+            }
+            *(bf16x8*)(tl + (i * RPS + pr) * PITCH + c * 2) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (32 * s + 8 * kg < C) a = *(const bf16x8*)(tl + col * PITCH + (32 * s + 8 * kg) * 2);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[s], acc, 0, 0, 0);
+        }
+        // D[i = pixel 4 kg + e][j = class col]
+        if (col < NC) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t r = r0 + 4 * kg + e;
+                if (r < rows) seg[r * lds_ + col] = (bf16)(acc[e] + bias);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+static inline bool cls_ok(int C, int nc) { const int ch = C / 8; return C % 8 == 0 && ch >= 1 && ch <= 64 && (ch & (ch - 1)) == 0 && nc >= 1 && nc <= 8; }
+#define SS_NC_SWITCH(nc, ...) do { switch (nc) { \
+        case 1: { constexpr int NC = 1; __VA_ARGS__; } break; case 2: { constexpr int NC = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int NC = 3; __VA_ARGS__; } break; case 4: { constexpr int NC = 4; __VA_ARGS__; } break; \
+        case 5: { constexpr int NC = 5; __VA_ARGS__; } break; case 6: { constexpr int NC = 6; __VA_ARGS__; } break; \
+        case 7: { constexpr int NC = 7; __VA_ARGS__; } break; default: { constexpr int NC = 8; __VA_ARGS__; } break; } } while (0)
+
+extern "C" int ss_bn_apply_classify(int dtype, const void* z, int64_t ldz, const float* stats, const float* gamma, const float* beta,
+                                    const float* mask, int64_t rows_per_image, const float* wp, const float* bp, int nc, void* seg,
+                                    int64_t lds_, int64_t rows, int C, hipStream_t stream) {
+    SS_CHECK(z && stats && gamma && beta && wp && bp && seg && rows > 0 && cls_ok(C, nc), "ss_bn_apply_classify: bad arguments (C=%d: 8 * power of two <= 512; nc=%d <= 8)", C, nc);
+    SS_CHECK(ldz >= C && ldz % 8 == 0 && lds_ >= nc && aligned16(z), "ss_bn_apply_classify: bad leading dimensions");
+    SS_CHECK(!mask || rows_per_image > 0, "ss_bn_apply_classify: rows_per_image required with a mask");
+    ColGeom g = col_geom(rows, C);
+    BnWalk w{g.cpb, g.rpb};
+    const int blocks = bn_walk_blocks(rows, g.rpb), sh = pow2_shift(rows_per_image);
+    if (dtype == SS_BF16 && C >= 32) {
+        int64_t nt = cdiv(cdiv(rows, 16), 4);
+        const int grid = (int)(nt < 4096 ? nt : 4096);
+#define SS_CLS_MFMA(CPB) do { SS_NC_SWITCH(nc, { \
+            if (mask) hipLaunchKernelGGL((bn_apply_cls_mfma_kernel<NC, true, CPB>), dim3(grid), dim3(256), 0, stream, (const bf16*)z, ldz, stats, gamma, beta, \
+                                         mask, rows_per_image, sh, wp, bp, (bf16*)seg, lds_, rows); \
+            else hipLaunchKernelGGL((bn_apply_cls_mfma_kernel<NC, false, CPB>), dim3(grid), dim3(256), 0, stream, (const bf16*)z, ldz, stats, gamma, beta, \
+                                    mask, rows_per_image, sh, wp, bp, (bf16*)seg, lds_, rows); }); } while (0)
+        switch (C / 8) { case 4: SS_CLS_MFMA(4); break; case 8: SS_CLS_MFMA(8); break; case 16: SS_CLS_MFMA(16); break;
+                         case 32: SS_CLS_MFMA(32); break; default: SS_CLS_MFMA(64); break; }
+#undef SS_CLS_MFMA
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
+    SS_DISPATCH(dtype, SS_NC_SWITCH(nc, {
+        if (mask) hipLaunchKernelGGL((bn_apply_cls_kernel<T, NC, true>), dim3(blocks), dim3(256), 0, stream, (const T*)z, ldz, stats, gamma, beta, mask,
+                                     rows_per_image, sh, wp, bp, (T*)seg, lds_, rows, C, w);
+        else hipLaunchKernelGGL((bn_apply_cls_kernel<T, NC, false>), dim3(blocks), dim3(256), 0, stream, (const T*)z, ldz, stats, gamma, beta, mask,
+                                rows_per_image, sh, wp, bp, (T*)seg, lds_, rows, C, w);
+    }));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// workspace: nb*2*C (BatchNorm partials) + 2*C (coefficients) + nb*nc*C (classifier weight-gradient partials) floats, nb <= 1024
+extern "C" int ss_bn_bwd_classify(int dtype, const void* dseg, int64_t ldd, const void* z, int64_t ldz, const float* stats, const float* gamma,
+                                  const float* beta, const float* mask, int64_t rows_per_image, int training, const float* wp, int nc, void* dz,
+                                  int64_t ldo, float* dgamma_dbeta, float* dwp, int64_t rows, int C, float* workspace, int64_t ws_bytes,
+                                  hipStream_t stream) {
+    SS_CHECK(dseg && z && stats && gamma && beta && wp && dz && dgamma_dbeta && dwp && workspace && rows > 0 && cls_ok(C, nc),
+             "ss_bn_bwd_classify: bad arguments (C=%d: 8 * power of two <= 512; nc=%d <= 8)", C, nc);
+    SS_CHECK(ldd >= nc && ldz >= C && ldo >= C && ldz % 8 == 0 && ldo % 8 == 0 && aligned16(z) && aligned16(dz), "ss_bn_bwd_classify: bad leading dimensions");
+    SS_CHECK(!mask || rows_per_image > 0, "ss_bn_bwd_classify: rows_per_image required with a mask");
+    ColGeom g = col_geom(rows, C);
+    SS_CHECK(ws_bytes >= ((int64_t)g.nb * (2 + nc) * C + 2 * C) * 4, "ss_bn_bwd_classify: workspace too small");
+    float* coef = workspace + (int64_t)g.nb * 2 * C;
+    float* part2 = coef + 2 * C;
+    BnWalk w{g.cpb, g.rpb};
+    const int blocks2 = bn_walk_blocks(rows, g.rpb), sh = pow2_shift(rows_per_image);
+#define SS_BN_CLS(MASK, P2, GRID) hipLaunchKernelGGL((bn_bwd_cls_kernel<T, NC, MASK, P2>), dim3(GRID), dim3(256), 0, stream, (const T*)dseg, ldd, (const T*)z, ldz, \
+        stats, gamma, beta, mask, rows_per_image, sh, wp, coef, (T*)dz, ldo, workspace, part2, rows, C, w)
+    SS_DISPATCH(dtype, SS_NC_SWITCH(nc, {
+        if (mask) SS_BN_CLS(true, false, g.nb); else SS_BN_CLS(false, false, g.nb);
+    }));
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, g.nb, C, rows, training, dgamma_dbeta, coef);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv((int64_t)nc * C, 8), 1), dim3(256), 0, stream, part2, g.nb, nc * C, 1.f, dwp, 0);
+    SS_LAUNCH_CHECK();
+    SS_DISPATCH(dtype, SS_NC_SWITCH(nc, {
+        if (mask) SS_BN_CLS(true, true, blocks2); else SS_BN_CLS(false, true, blocks2);
+    }));
+#undef SS_BN_CLS
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------ helpers for narrow / sliced tensors
 // column sums of a narrow matrix (C <= 32, any C): out[c] = sum_r x[r][c]   (e.g. the bias gradient of the nc-class classifier)
 template <typename T>

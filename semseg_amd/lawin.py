@@ -139,9 +139,16 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     ops.gemm_nt(t[0], w_fwd(P['linear_c1.proj.weight'], T), bias=P['linear_c1.proj.bias'], out=cat2[:, E:])
     zl = ops.gemm_nt(cat2, _conv_w(P['low_level_fuse.conv.weight'], T))
     stl = _bn_stats(zl, P, Bf, 'low_level_fuse.bn', training)
-    fused = ops.bn_apply(zl, stl, P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'], act=1, mask=drop_mask,
-                         rows_per_image=H4 * W4 if drop_mask is not None else 0)
-    seg = ops.gemm_nt(fused, _conv_w(P['linear_pred.weight'], T), bias=P['linear_pred.bias'])
+    nc = P['linear_pred.weight'].shape[0]
+    rpi4 = H4 * W4 if drop_mask is not None else 0
+    if ops.bn_classify_ok(E, nc):
+        # BatchNorm + Mish + Dropout2d + classifier in one pass: the E-channel activation at S/4 is never written
+        fused = None
+        seg = ops.bn_apply_classify(zl, stl, P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'],
+                                    P['linear_pred.weight'].detach().view(nc, E), P['linear_pred.bias'].detach(), mask=drop_mask, rows_per_image=rpi4)
+    else:
+        fused = ops.bn_apply(zl, stl, P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'], act=1, mask=drop_mask, rows_per_image=rpi4)
+        seg = ops.gemm_nt(fused, _conv_w(P['linear_pred.weight'], T), bias=P['linear_pred.bias'])
     S.update(z8=z8, stc=stc, cat2=cat2, zl=zl, stl=stl, fused=fused, drop_mask=drop_mask, training=training)
     return seg, S
 
@@ -158,11 +165,17 @@ def head_backward(P, S, dseg, E):
         G[prefix + '.weight'], G[prefix + '.bias'] = dgb[0], dgb[1]
 
     # classifier + low-level fuse
-    G['linear_pred.weight'] = ops.gemm_tn(dseg, S['fused'])
     G['linear_pred.bias'] = ops.colsum_any(dseg)
-    dfused = ops.gemm_nt(dseg, w_bwd(P['linear_pred.weight'], T))
-    dzl, dgb = ops.bn_bwd(dfused, S['zl'], S['stl'], P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'], act=1, mask=mask,
-                          rows_per_image=rpi4, training=training)
+    if S['fused'] is None:
+        nc = P['linear_pred.weight'].shape[0]
+        dzl, dgb, G['linear_pred.weight'] = ops.bn_bwd_classify(dseg, S['zl'], S['stl'], P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'],
+                                                                P['linear_pred.weight'].detach().view(nc, E), mask=mask, rows_per_image=rpi4,
+                                                                training=training)
+    else:
+        G['linear_pred.weight'] = ops.gemm_tn(dseg, S['fused'])
+        dfused = ops.gemm_nt(dseg, w_bwd(P['linear_pred.weight'], T))
+        dzl, dgb = ops.bn_bwd(dfused, S['zl'], S['stl'], P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'], act=1, mask=mask,
+                              rows_per_image=rpi4, training=training)
     bn_grads('low_level_fuse.bn', dgb)
     G['low_level_fuse.conv.weight'] = ops.gemm_tn(dzl, S['cat2'])
     dcat2 = ops.gemm_nt(dzl, w_bwd(P['low_level_fuse.conv.weight'], T))

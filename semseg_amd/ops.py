@@ -486,6 +486,53 @@ def bn_bwd_up(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True
     return out, dgb
 
 
+# ------------------------------------------------------------------ BatchNorm + Mish + Dropout2d + narrow classifier in one pass
+def bn_classify_ok(C, nc):
+    ch = C // 8
+    return C % 8 == 0 and 1 <= ch <= 64 and ch & (ch - 1) == 0 and 1 <= nc <= 8
+
+
+def _cls_args(z, wp, mask, rows_per_image, name):
+    rows, C, ldz = _mat(z, 'z')
+    nc = wp.shape[0]
+    _f32(wp, 'wp', nc * C)
+    if not bn_classify_ok(C, nc):
+        raise ValueError(f'{name}: C must be 8 * a power of two <= 512 and nc <= 8 (got C={C}, nc={nc})')
+    if mask is not None:
+        _f32(mask, 'mask')
+        if rows_per_image <= 0 or mask.numel() * rows_per_image != rows * C:
+            raise ValueError(f'{name}: bad mask')
+    return rows, C, ldz, nc
+
+
+def bn_apply_classify(z, stats, gamma, beta, wp, bp, mask=None, rows_per_image=0):
+    """seg[rows, nc] = (mask * Mish(BN(z))) @ wp^T + bp; the activation is never written."""
+    dev = _dev(z)
+    rows, C, ldz, nc = _cls_args(z, wp, mask, rows_per_image, 'bn_apply_classify')
+    _f32(stats, 'stats', 2 * C), _f32(gamma, 'gamma', C), _f32(beta, 'beta', C), _f32(bp, 'bp', nc)
+    seg = torch.empty((rows, nc), dtype=z.dtype, device=dev)
+    check(lib().ss_bn_apply_classify(dt(z), _p(z), ldz, _p(stats), _p(gamma), _p(beta), _p(mask), rows_per_image, _p(wp), _p(bp), nc,
+                                     _p(seg), nc, rows, C, _stream()))
+    return seg
+
+
+def bn_bwd_classify(dseg, z, stats, gamma, beta, wp, mask=None, rows_per_image=0, training=True):
+    """-> dz [rows, C], dgb [2,C] (dgamma, dbeta), dwp [nc, C] fp32."""
+    dev = _dev(z)
+    rows, C, ldz, nc = _cls_args(z, wp, mask, rows_per_image, 'bn_bwd_classify')
+    rd, ncd, ldd = _mat(dseg, 'dseg')
+    if (rd, ncd) != (rows, nc) or dseg.dtype != z.dtype:
+        raise ValueError('bn_bwd_classify: dseg mismatch')
+    _f32(stats, 'stats', 2 * C), _f32(gamma, 'gamma', C), _f32(beta, 'beta', C)
+    dz = torch.empty((rows, C), dtype=z.dtype, device=dev)
+    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    dwp = torch.empty((nc, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, (COLRED_BLOCKS * (2 + nc) * C + 2 * C) * 4)
+    check(lib().ss_bn_bwd_classify(dt(z), _p(dseg), ldd, _p(z), ldz, _p(stats), _p(gamma), _p(beta), _p(mask), rows_per_image, int(training),
+                                   _p(wp), nc, _p(dz), C, _p(dgb), _p(dwp), rows, C, _p(ws), ws.numel(), _stream()))
+    return dz, dgb, dwp
+
+
 # ------------------------------------------------------------------ casts / packing / elementwise
 def cast(x, dtype):
     _dev(x)

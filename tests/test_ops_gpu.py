@@ -241,6 +241,49 @@ def test_batchnorm_of_bilinear_resize(ops, dtype, B, hi, wi, ho, wo, C, act):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('rows,C,nc,masked', [(2000, 64, 6, True), (333, 128, 8, False), (4100, 512, 6, True), (70, 8, 2, False), (1026, 256, 3, True)])
+def test_batchnorm_mish_classifier(ops, dtype, rows, C, nc, masked):
+    """ss_bn_apply_classify / ss_bn_bwd_classify (LawinHead tail, modules/lawin.py:101-105,227-228: BatchNorm2d + Mish + Dropout2d +
+    1x1 classifier) against torch fp32 and against the unfused ss_bn_apply + ss_gemm_nt / ss_gemm_tn + ss_bn_bwd sequence."""
+    B = 2 if rows % 2 == 0 else 1
+    z, g, b = rnd(rows, C, scale=1.5) + 0.3, 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
+    wp, bp, dseg = rnd(nc, C, seed=7) / math.sqrt(C), 0.1 * rnd(nc, seed=8), rnd(rows, nc, seed=9)
+    mask = (torch.rand(B, C, generator=torch.Generator().manual_seed(1)) > 0.3).float() / 0.7 if masked else None
+    rpi = rows // B if masked else 0
+    zr = q(z, dtype).requires_grad_(True)
+    gr, br, wr = g.clone().requires_grad_(True), b.clone().requires_grad_(True), wp.clone().requires_grad_(True)
+    u = F.mish(F.batch_norm(zr.t()[None], None, None, gr, br, True, 0.1, 1e-5)[0].t())
+    if masked:
+        u = u * mask.repeat_interleave(rows // B, 0)
+    ref = u @ wr.t() + bp
+    ref.backward(q(dseg, dtype))
+    zd, md = dev(z, dtype), (dev(mask) if masked else None)
+    stats = ops.bn_stats(zd)
+    seg = ops.bn_apply_classify(zd, stats, dev(g), dev(b), dev(wp), dev(bp), mask=md, rows_per_image=rpi)
+    assert seg.dtype == dtype and rel(seg, ref) < _tol(dtype)
+    dz, dgb, dwp = ops.bn_bwd_classify(dev(dseg, dtype), zd, stats, dev(g), dev(b), dev(wp), mask=md, rows_per_image=rpi)
+    assert rel(dz, zr.grad) < _gtol(dtype)
+    wtol = 1e-4 if dtype == torch.float32 else 2e-3          # bf16: the logit gradients are bf16, the sums fp32
+    assert rel(dgb[0], gr.grad) < wtol and rel(dgb[1], br.grad) < wtol and rel(dwp, wr.grad) < wtol
+    # the unfused sequence on the same inputs (it rounds the activation and its gradient to the storage dtype)
+    fused = ops.bn_apply(zd, stats, dev(g), dev(b), 1, mask=md, rows_per_image=rpi)
+    seg2 = ops.gemm_nt(fused, dev(wp, dtype), bias=dev(bp))
+    dfused = ops.gemm_nt(dev(dseg, dtype), dev(wp.t().contiguous(), dtype))
+    dz2, dgb2 = ops.bn_bwd(dfused, zd, stats, dev(g), dev(b), 1, mask=md, rows_per_image=rpi)
+    assert rel(seg, seg2) < _tol(dtype) and rel(dz, dz2) < _gtol(dtype) and rel(dgb, dgb2) < (1e-4 if dtype == torch.float32 else 1e-2)
+    # eval mode: running statistics, dz without the batch terms
+    rm, rv = 0.1 * rnd(C, seed=5), 1 + 0.1 * rnd(C, seed=6).abs()
+    zr2 = q(z, dtype).requires_grad_(True)
+    u2 = F.mish(F.batch_norm(zr2.t()[None], rm, rv, g, b, False, 0.1, 1e-5)[0].t())
+    ref2 = u2 @ wp.t() + bp
+    ref2.backward(q(dseg, dtype))
+    st2 = ops.bn_eval_stats(dev(rm), dev(rv))
+    assert rel(ops.bn_apply_classify(zd, st2, dev(g), dev(b), dev(wp), dev(bp)), ref2) < _tol(dtype)
+    dz3, _, _ = ops.bn_bwd_classify(dev(dseg, dtype), zd, st2, dev(g), dev(b), dev(wp), training=False)
+    assert rel(dz3, zr2.grad) < _gtol(dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_colsum(ops, dtype):
     x = rnd(3 * 500, 64)
     out = ops.colsum(dev(x, dtype), groups=3, scale=0.5)
