@@ -350,244 +350,19 @@ extern "C" int ss_bn_stats(int dtype, const void* x, int64_t ld, int64_t rows, i
 // bits as the generic formula).  The horizontal lerps of an input row are computed once and serve the four output rows that use
 // it; three lerped rows (p-1, p, p+1) rotate through registers and rows p+2 .. p+4 are in flight: one new input row (4 loads, 2
 // of them the same line) and 2 x 8 x 2 horizontal + 4 x 8 x 2 vertical flops per FOUR output chunks.
-struct Up2Geom { int cpb, xl, groups, xtiles, ystrips, tp, chunks; };
-static inline Up2Geom up2_geom(int B, int hi, int wi, int C) {
-    Up2Geom g; g.chunks = C / 8;
-    int cpb = 1; while (cpb < g.chunks && cpb < 64) cpb <<= 1;
-    g.cpb = cpb; g.xl = 256 / cpb; g.groups = (int)cdiv(g.chunks, cpb);
-    g.xtiles = (int)cdiv(wi, g.xl);
-    int tp = 24;                                           // row pairs per strip (a multiple of 3: the window rotates through 3 slots)
-    while (tp > 6 && (int64_t)B * g.xtiles * cdiv(hi, tp) * g.groups < 4096) tp -= 6;
-    g.tp = tp; g.ystrips = (int)cdiv(hi, tp);
-    return g;
+// UN channels per thread: with 8 the window rows, the rows in flight and the per-channel constants take 250-350 registers (one
+// wave per SIMD), which only the store-heavy apply kernel tolerates (16-byte stores: 350 us against 460 with 8-byte ones); the
+// statistics and backward kernels are bound by their vector arithmetic (Mish') and run with 4 (140-200 registers).
+#define UN 8
+namespace w8 {
+#include "bn_up2_inc.h"
 }
-template <typename T> struct Up2Row { Raw8<T> a0, b0, a1, b1; };
-template <typename T> struct Up2 {
-    const T* base; int64_t rs, oA0, oB0, oA1, oB1; int hi; float l00, l01, l10, l11;
-    __device__ __forceinline__ void init(const T* x, int64_t ld, int hi_, int wi, int img, int j, int c) {
-        const int jc = min(max(j, 0), wi - 1);
-        const LinTap t0 = lin_tap(2 * jc, 0.5f, wi), t1 = lin_tap(2 * jc + 1, 0.5f, wi);
-        hi = hi_; rs = (int64_t)wi * ld; base = x + (int64_t)img * hi * rs + c;
-        oA0 = t0.i0 * ld; oB0 = t0.i1 * ld; oA1 = t1.i0 * ld; oB1 = t1.i1 * ld;
-        l00 = t0.l0; l01 = t0.l1; l10 = t1.l0; l11 = t1.l1;
-    }
-    __device__ __forceinline__ void issue(int row, Up2Row<T>& r) const {
-        const T* p = base + (int64_t)min(max(row, 0), hi - 1) * rs;
-        r.a0.load(p + oA0); r.b0.load(p + oB0); r.a1.load(p + oA1); r.b1.load(p + oB1);
-    }
-    __device__ __forceinline__ void hlerp(const Up2Row<T>& r, float (&h)[2][8]) const {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            h[0][e] = fmaf(l01, r.b0.get(e), l00 * r.a0.get(e));
-            h[1][e] = fmaf(l11, r.b1.get(e), l10 * r.a1.get(e));
-        }
-    }
-};
-// the two output rows of pair p from the lerped input rows p-1, p, p+1: z[r][col][e], rounded to T as ss_bilinear_fwd stores them
-template <typename T>
-__device__ __forceinline__ void up2_rows(int p, int hi, const float (&prev)[2][8], const float (&cur)[2][8], const float (&next)[2][8],
-                                         float (&z)[2][2][8]) {
-    const LinTap te = lin_tap(2 * p, 0.5f, hi), to = lin_tap(2 * p + 1, 0.5f, hi);
-#pragma unroll
-    for (int col = 0; col < 2; ++col)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            z[0][col][e] = to_f(from_f<T>(fmaf(te.l1, cur[col][e], te.l0 * prev[col][e])));
-            z[1][col][e] = to_f(from_f<T>(fmaf(to.l1, next[col][e], to.l0 * cur[col][e])));
-        }
+#undef UN
+#define UN 4
+namespace w4 {
+#include "bn_up2_inc.h"
 }
-// Shared frame of the walker kernels.  body(p, z) runs once per row pair p in [ps, ps + 3 * ceil((pe - ps) / 3)): pairs >= pe are
-// computed from clamped rows and must be ignored by the body.
-template <typename T, typename F>
-__device__ __forceinline__ void up2_walk(const Up2<T>& U, int ps, int pe, F&& body) {
-    float H[3][2][8]; Up2Row<T> ring[3];
-    { Up2Row<T> r; U.issue(ps - 1, r); U.hlerp(r, H[0]); U.issue(ps, r); U.hlerp(r, H[1]); U.issue(ps + 1, r); U.hlerp(r, H[2]); }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) U.issue(ps + 2 + i, ring[i]);
-    for (int p0 = ps; p0 < pe; p0 += 3) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int p = p0 + i;
-            float z[2][2][8];
-            up2_rows<T>(p, U.hi, H[i % 3], H[(i + 1) % 3], H[(i + 2) % 3], z);
-            body(p, z);
-            U.hlerp(ring[i], H[i % 3]);                      // row p + 2 takes the slot of row p - 1
-            U.issue(p + 5, ring[i]);
-        }
-    }
-}
-
-struct Up2Tile { int img, j, ps, pe; bool colok; };
-__device__ __forceinline__ Up2Tile up2_tile(int tile, const Up2Geom& g, int hi, int wi, int xs) {
-    const int per_img = g.xtiles * g.ystrips;
-    Up2Tile t; t.img = tile / per_img; const int rem = tile - t.img * per_img;
-    const int ys = rem / g.xtiles, xt = rem - ys * g.xtiles;
-    t.j = xt * g.xl + xs; t.colok = t.j < wi;
-    t.ps = ys * g.tp; t.pe = min(hi, t.ps + g.tp);
-    return t;
-}
-
-// partial[blockIdx.x][0][c] = sum (z - shift), [1] = sum (z - shift)^2 over this workgroup's tiles, shift = x[0][c]
-template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_up2_kernel(const T* __restrict__ x, int64_t ld, int B, int hi, int wi, int C, Up2Geom g,
-                                                           float* __restrict__ partial) {
-    __shared__ float red[256 * 8];
-    const int tid = threadIdx.x, cl = tid % g.cpb, xs = tid / g.cpb;
-    const int chunk_raw = blockIdx.y * g.cpb + cl;
-    const bool cok = chunk_raw < g.chunks;
-    const int c = (cok ? chunk_raw : g.chunks - 1) * 8;
-    float acc[2][8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
-    const F8 sh = load8(x + c);
-    const int ntiles = B * g.xtiles * g.ystrips;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const Up2Tile t = up2_tile(tile, g, hi, wi, xs);
-        Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c);
-        up2_walk<T>(U, t.ps, t.pe, [&](int p, const float (&z)[2][2][8]) {
-            const float live = (t.colok && cok && p < t.pe) ? 1.f : 0.f;
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int col = 0; col < 2; ++col)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = (z[r][col][e] - sh.v[e]) * live; acc[0][e] += d; acc[1][e] = fmaf(d, d, acc[1][e]); }
-        });
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[k][e];
-        __syncthreads();
-        if (xs == 0 && cok) {
-            float* dst = partial + ((int64_t)blockIdx.x * 2 + k) * C + c;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { float s = 0.f;
-                for (int q = 0; q < g.xl; ++q) s += red[(q * g.cpb + cl) * 8 + e];
-                dst[e] = s; }
-        }
-    }
-}
-
-// y[2p + r][2j + col] = act(gamma * (z - mean) * rstd + beta)
-template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_apply_up2_kernel(const T* __restrict__ x, int64_t ld, int hi, int wi, const float* __restrict__ stats,
-        const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, int64_t ldy, int C, Up2Geom g) {
-    const int tid = threadIdx.x, cl = tid % g.cpb, xs = tid / g.cpb;
-    const int chunk = blockIdx.y * g.cpb + cl;
-    if (chunk >= g.chunks) return;
-    const int c = chunk * 8;
-    const Up2Tile t = up2_tile(blockIdx.x, g, hi, wi, xs);
-    if (!t.colok) return;
-    F8 sc, sh;
-    { F8 mu = load8(stats + c), rs = load8(stats + C + c), gm = load8(gamma + c), b = load8(beta + c);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { sc.v[e] = rs.v[e] * gm.v[e]; sh.v[e] = b.v[e] - mu.v[e] * sc.v[e]; } }
-    const int wo = 2 * wi;
-    T* yb = y + ((int64_t)t.img * 2 * hi * wo + 2 * t.j) * ldy + c;
-    Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c);
-    up2_walk<T>(U, t.ps, t.pe, [&](int p, const float (&z)[2][2][8]) {
-        if (p < t.pe) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int col = 0; col < 2; ++col) {
-                    F8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { float u = fmaf(z[r][col][e], sc.v[e], sh.v[e]); o.v[e] = ACT == 1 ? mish_f(u) : u; }
-                    store8(yb + ((int64_t)(2 * p + r) * wo + col) * ldy, o);
-                }
-        }
-    });
-}
-
-// backward over the resized map: PASS2 = false: partial sums of g and g * xhat; true: dz (the gradient of the resized map)
-template <typename T, int ACT, bool PASS2>
-__global__ __launch_bounds__(256) void bn_bwd_up2_kernel(const T* __restrict__ dy, int64_t ldd, const T* __restrict__ x, int64_t ld, int B, int hi, int wi,
-        const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ coef,
-        T* __restrict__ dz, int64_t ldo, float* __restrict__ partial, int C, Up2Geom g) {
-    __shared__ float red[PASS2 ? 1 : 256 * 8];
-    const int tid = threadIdx.x, cl = tid % g.cpb, xs = tid / g.cpb;
-    const int chunk_raw = blockIdx.y * g.cpb + cl;
-    const bool cok = chunk_raw < g.chunks;
-    const int c = (cok ? chunk_raw : g.chunks - 1) * 8;
-    float acc[2][8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
-    F8 xs_, xo, gm, bt, k0, k1, k2;                          // xhat = z * xs + xo;  dz = k0 * g + k1 + xhat * k2
-    { F8 mu = load8(stats + c), rs = load8(stats + C + c);
-      gm = load8(gamma + c); bt = load8(beta + c);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { xs_.v[e] = rs.v[e]; xo.v[e] = -mu.v[e] * rs.v[e]; }
-      if (PASS2) { F8 c1 = load8(coef + c), c2 = load8(coef + C + c);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { k0.v[e] = gm.v[e] * rs.v[e]; k1.v[e] = -k0.v[e] * c1.v[e]; k2.v[e] = -k0.v[e] * c2.v[e]; } } }
-    const int wo = 2 * wi, ntiles = B * g.xtiles * g.ystrips;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const Up2Tile t = up2_tile(tile, g, hi, wi, xs);
-        const int jc = min(t.j, wi - 1);
-        const int64_t ob = (int64_t)t.img * 2 * hi * wo + 2 * jc;
-        const T* db = dy + ob * ldd + c;
-        T* zb = dz + ob * ldo + c;
-        const bool live_t = t.colok && cok;
-        Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c);
-        Raw8<T> dn[2][2];                                    // dy of the pair about to be consumed
-        { const int pp = min(t.ps, hi - 1);
-#pragma unroll
-          for (int r = 0; r < 2; ++r)
-#pragma unroll
-              for (int col = 0; col < 2; ++col) dn[r][col].load(db + ((int64_t)(2 * pp + r) * wo + col) * ldd); }
-        up2_walk<T>(U, t.ps, t.pe, [&](int p, const float (&z)[2][2][8]) {
-            Raw8<T> d[2][2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int col = 0; col < 2; ++col) d[r][col] = dn[r][col];
-            { const int pp = min(p + 1, hi - 1);
-#pragma unroll
-              for (int r = 0; r < 2; ++r)
-#pragma unroll
-                  for (int col = 0; col < 2; ++col) dn[r][col].load(db + ((int64_t)(2 * pp + r) * wo + col) * ldd); }
-            const bool live = live_t && p < t.pe;
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int col = 0; col < 2; ++col) {
-                    F8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float xh = fmaf(z[r][col][e], xs_.v[e], xo.v[e]);
-                        float gg = d[r][col].get(e);
-                        if (ACT == 1) gg *= mish_grad(fmaf(xh, gm.v[e], bt.v[e]));
-                        if (PASS2) o.v[e] = fmaf(k0.v[e], gg, fmaf(xh, k2.v[e], k1.v[e]));
-                        else if (live) { acc[0][e] += gg; acc[1][e] = fmaf(gg, xh, acc[1][e]); }
-                    }
-                    if (PASS2 && live) store8(zb + ((int64_t)(2 * p + r) * wo + col) * ldo, o);
-                }
-        });
-    }
-    if (!PASS2) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[k][e];
-            __syncthreads();
-            if (xs == 0 && cok) {
-                float* dst = partial + ((int64_t)blockIdx.x * 2 + k) * C + c;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { float s = 0.f;
-                    for (int q = 0; q < g.xl; ++q) s += red[(q * g.cpb + cl) * 8 + e];
-                    dst[e] = s; }
-            }
-        }
-    }
-}
-static inline int up2_blocks(const Up2Geom& g, int B) {
-    const int64_t t = (int64_t)B * g.xtiles * g.ystrips;
-    return (int)(t < SS_COLRED_MAX_BLOCKS ? t : SS_COLRED_MAX_BLOCKS);
-}
+#undef UN
 static inline bool up2_ok(int hi, int wi, int ho, int wo) { return ho == 2 * hi && wo == 2 * wi; }
 
 #define SS_UP_CHECK(name) \
@@ -603,6 +378,7 @@ extern "C" int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, int B, int 
     SS_CHECK(ws_bytes >= (int64_t)g.nb * 2 * C * 4, "ss_bn_stats_up: workspace too small");
     int nb = g.nb;
     if (up2_ok(hi, wi, ho, wo)) {
+        using namespace w4;
         const Up2Geom u = up2_geom(B, hi, wi, C);
         nb = up2_blocks(u, B);
         SS_DISPATCH(dtype, hipLaunchKernelGGL((bn_stats_up2_kernel<T>), dim3(nb, u.groups), dim3(256), 0, stream, (const T*)x, ldx, B, hi, wi, C, u, workspace));
@@ -728,6 +504,7 @@ extern "C" int ss_bn_apply_up(int dtype, const void* x, int64_t ldx, int B, int 
 #define SS_BN_APPLY_UP(ACT) hipLaunchKernelGGL((bn_apply_kernel<T, ACT, false, false, true>), dim3(blocks), dim3(256), 0, stream, (const T*)x, ldx, \
         stats, gamma, beta, (const T*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, -1, (T*)y, ldy, rows, C, w, up)
     if (up2_ok(hi, wi, ho, wo)) {
+        using namespace w8;
         const Up2Geom u = up2_geom(B, hi, wi, C);
         dim3 grid((unsigned)(B * u.xtiles * u.ystrips), (unsigned)u.groups);
         SS_DISPATCH(dtype, {
@@ -890,6 +667,7 @@ extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* 
 #define SS_BN_BWD_UP(ACT, P2, GRID) hipLaunchKernelGGL((bn_bwd_kernel<T, ACT, false, P2, true>), dim3(GRID), dim3(256), 0, stream, (const T*)dy, ldd, \
         (const T*)x, ldx, stats, gamma, beta, (const float*)nullptr, (int64_t)0, -1, coef, (T*)dz, ldo, workspace, rows, C, w, up)
     if (up2_ok(hi, wi, ho, wo)) {
+        using namespace w4;
         const Up2Geom u = up2_geom(B, hi, wi, C);
         const int nb = up2_blocks(u, B);
         dim3 g1((unsigned)nb, (unsigned)u.groups), g2((unsigned)(B * u.xtiles * u.ystrips), (unsigned)u.groups);
@@ -914,6 +692,42 @@ extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* 
         if (act) SS_BN_BWD_UP(1, true, blocks2); else SS_BN_BWD_UP(0, true, blocks2);
     });
 #undef SS_BN_BWD_UP
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// x2 only: pass 1 as ss_bn_bwd_up, pass 2 returns dx [B*hi*wi, C] = ss_bilinear_bwd(dz) directly (dz is never written)
+extern "C" int ss_bn_bwd_up2_dx(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, int B, int hi, int wi,
+                                const float* stats, const float* gamma, const float* beta, int training, void* dx, int64_t ldo,
+                                float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(dy && x && stats && gamma && beta && dx && dgamma_dbeta && workspace && C > 0 && C % 8 == 0, "ss_bn_bwd_up2_dx: bad arguments");
+    SS_CHECK(ldd >= C && ldx >= C && ldo >= C && ldd % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && aligned16(dy) && aligned16(x) && aligned16(dx),
+             "ss_bn_bwd_up2_dx: bad leading dimensions");
+    SS_CHECK(act == 0 || act == 1, "ss_bn_bwd_up2_dx: act must be 0 (none) or 1 (Mish)");
+    const int ho = 2 * hi, wo = 2 * wi;
+    SS_UP_CHECK("ss_bn_bwd_up2_dx");
+    const int64_t rows = (int64_t)B * ho * wo;
+    ColGeom g = col_geom(rows, C);
+    SS_CHECK(ws_bytes >= ((int64_t)g.nb * 2 * C + 2 * C) * 4, "ss_bn_bwd_up2_dx: workspace too small");
+    float* coef = workspace + (int64_t)g.nb * 2 * C;
+    using namespace w4;
+    const Up2Geom u = up2_geom(B, hi, wi, C);
+    const int nb = up2_blocks(u, B);
+    const Up2DxGeom u2 = up2dx_geom(B, hi, wi, C);
+    dim3 g1((unsigned)nb, (unsigned)u.groups), g2((unsigned)(B * u2.xtiles * u2.ystrips), (unsigned)u2.groups);
+    SS_DISPATCH(dtype, {
+        if (act) hipLaunchKernelGGL((bn_bwd_up2_kernel<T, 1, false>), g1, dim3(256), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, B, hi, wi, stats, gamma, beta,
+                                    coef, (T*)nullptr, (int64_t)0, workspace, C, u);
+        else hipLaunchKernelGGL((bn_bwd_up2_kernel<T, 0, false>), g1, dim3(256), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, B, hi, wi, stats, gamma, beta,
+                                coef, (T*)nullptr, (int64_t)0, workspace, C, u);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, nb, C, rows, training, dgamma_dbeta, coef);
+        SS_LAUNCH_CHECK();
+        if (act) hipLaunchKernelGGL((bn_bwd_up2_dx_kernel<T, 1>), g2, dim3(512), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, hi, wi, stats, gamma, beta, coef,
+                                    (T*)dx, ldo, C, u2);
+        else hipLaunchKernelGGL((bn_bwd_up2_dx_kernel<T, 0>), g2, dim3(512), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, hi, wi, stats, gamma, beta, coef,
+                                (T*)dx, ldo, C, u2);
+    });
     SS_LAUNCH_CHECK();
     return 0;
 }

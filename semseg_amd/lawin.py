@@ -183,9 +183,9 @@ def head_backward(P, S, dseg, E):
     G['linear_c1.proj.weight'], G['linear_c1.proj.bias'] = ops.gemm_tn(dc1, t[0], colsum=True)
     dt = [ops.gemm_nt(dc1, w_bwd(P['linear_c1.proj.weight'], T)), None, None, None]
     # cat
-    dz4, dgb = ops.bn_bwd_up(dcat2[:, :E], S['z8'], B, H8, W8, H4, W4, S['stc'], P['cat.bn.weight'], P['cat.bn.bias'], act=1, training=training)
+    dz8, dgb = ops.bn_bwd_up_to_input(dcat2[:, :E], S['z8'], B, H8, W8, H4, W4, S['stc'], P['cat.bn.weight'], P['cat.bn.bias'], act=1,
+                                      training=training)
     bn_grads('cat.bn', dgb)
-    dz8 = ops.bilinear_bwd(dz4, B, H8, W8, H4, W4)
     G['cat.conv.weight'] = ops.gemm_tn(dz8, S['cat5'])
     dcat5 = ops.gemm_nt(dz8, w_bwd(P['cat.conv.weight'], T))
     feat = S['cat5'][:, :E]

@@ -486,6 +486,25 @@ def bn_bwd_up(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True
     return out, dgb
 
 
+def bn_bwd_up_to_input(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True):
+    """bilinear_bwd(bn_bwd_up(...)[0]) -> dx [B*hi*wi, C], dgb [2,C]; for the x2 resize the gradient of the resized map is never written."""
+    if (ho, wo) != (2 * hi, 2 * wi):
+        dz, dgb = bn_bwd_up(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=act, training=training)
+        return bilinear_bwd(dz, B, hi, wi, ho, wo), dgb
+    dev = _dev(x)
+    C, ldx = _up_args(x, B, hi, wi, 'bn_bwd_up_to_input')
+    rd, Cd, ldd = _mat(dy, 'dy')
+    if (rd, Cd) != (B * ho * wo, C) or dy.dtype != x.dtype:
+        raise ValueError('bn_bwd_up_to_input: dy mismatch')
+    _f32(stats, 'stats', 2 * C), _f32(gamma, 'gamma', C), _f32(beta, 'beta', C)
+    dx = torch.empty((B * hi * wi, C), dtype=x.dtype, device=dev)
+    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, (COLRED_BLOCKS * 2 * C + 2 * C) * 4)
+    check(lib().ss_bn_bwd_up2_dx(dt(x), _p(dy), ldd, _p(x), ldx, B, hi, wi, _p(stats), _p(gamma), _p(beta), int(training),
+                                 _p(dx), C, _p(dgb), C, act, _p(ws), ws.numel(), _stream()))
+    return dx, dgb
+
+
 # ------------------------------------------------------------------ BatchNorm + Mish + Dropout2d + narrow classifier in one pass
 def bn_classify_ok(C, nc):
     ch = C // 8

@@ -231,6 +231,9 @@ def test_batchnorm_of_bilinear_resize(ops, dtype, B, hi, wi, ho, wo, C, act):
     assert rel(dgb2[0], gr.grad) < (1e-4 if dtype == torch.float32 else 2e-3) and rel(dgb2[1], br.grad) < (1e-4 if dtype == torch.float32 else 2e-3)
     dx = ops.bilinear_bwd(dz2, B, hi, wi, ho, wo)
     assert rel(dx, xr.grad) < _gtol(dtype)
+    # second pass with the transpose of the resize folded in (x2), the unfused pair otherwise
+    dx2, dgb5 = ops.bn_bwd_up_to_input(dyd, xd, B, hi, wi, ho, wo, st1, dev(g), dev(b), act)
+    assert rel(dx2, xr.grad) < _gtol(dtype) and rel(dx2, dx) < (1e-5 if dtype == torch.float32 else 8e-3) and rel(dgb5, dgb2) < 1e-6
     # eval mode
     st3 = ops.bn_eval_stats(dev(rm), dev(rv))
     y3 = ops.bn_apply_up(xd, B, hi, wi, ho, wo, st3, dev(g), dev(b), act)
