@@ -61,9 +61,10 @@ __global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* _
         bf16* __restrict__ o, float* __restrict__ lse, int N, int Np, int Nk, int heads, int C, float c) {
     typedef AttnCfg<D> G;
     constexpr int CH = G::CH, NCH = G::NCH, PT = G::PT;
-    constexpr int SMEM = (G::SW + G::TR) > G::EPI ? (G::SW + G::TR) : G::EPI;
+    // two stages of (K image, V image): tile i+1 is stored while tile i is multiplied, one barrier per key tile
+    constexpr int STG = G::SW + G::TR;
+    constexpr int SMEM = 2 * STG > G::EPI ? 2 * STG : G::EPI;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
-    char* Ks = smem; char* Vt = smem + G::SW;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hd = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + wave) * 32;
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* _
             rv[i] = ok ? *(const bf16x8*)(src + C) : zero;
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int stage) {
+        char* Ks = smem + stage * STG; char* Vt = Ks + G::SW;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int cidx = tid + i * 256, row = cidx / CH, ch = cidx % CH;
@@ -100,11 +102,17 @@ __global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* _
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
     float m = -INFINITY, l = 0.f;
     gload(0);
-    lstore();
+    lstore(0);
+    if (64 < Nk) gload(64);
     __syncthreads();
-    for (int key0 = 0; key0 < Nk; key0 += 64) {
+    int stage = 0;
+    for (int key0 = 0; key0 < Nk; key0 += 64, stage ^= 1) {
         const bool more = key0 + 64 < Nk;
-        if (more) gload(key0 + 64);
+        const char* Ks = smem + stage * STG; const char* Vt = Ks + G::SW;
+        // tile i+1 (in registers since the previous iteration: a whole iteration of latency cover) goes to the other stage, which was
+        // last read before the previous iteration's barrier; tile i+2 starts travelling
+        if (more) lstore(stage ^ 1);
+        if (key0 + 128 < Nk) gload(key0 + 128);
         floatx16 s[2];
         MFMA_PRIO_UP();
 #pragma unroll
@@ -166,7 +174,6 @@ __global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* _
             }
         MFMA_PRIO_DOWN();
         __syncthreads();
-        if (more) { lstore(); __syncthreads(); }
     }
     l += __shfl_xor(l, 32, 64);
     if (h == 0 && q0 + j < N) lse[(int64_t)(b * heads + hd) * Np + q0 + j] = m + log2f(l);
