@@ -202,6 +202,10 @@ int ss_conv_patch_wgrad(int dtype, const void* dy, int64_t lddy, const void* x, 
  * resize of SURVEY.md §0.2), reading/writing channel slices (ldx/ldy) of concat buffers. */
 int ss_bilinear_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
                     hipStream_t stream);
+/* y += resize(x) (fp32 add, one rounding): the sum of up-sampled per-level maps of LawinHead.forward's concat + 1x1 conv
+ * (modules/lawin.py:183-199), with the conv commuted below the resize */
+int ss_bilinear_fwd_add(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
+                        hipStream_t stream);
 int ss_bilinear_bwd(int dtype, const void* dy, int64_t ldy, void* dx, int64_t ldx, int B, int hi, int wi, int ho, int wo, int C,
                     int accumulate, hipStream_t stream);
 

