@@ -96,19 +96,22 @@ int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, int64_t ldz
 /* The same three steps for a BatchNorm whose input is a bilinear resize (tnf.interpolate(..., mode='bilinear', align_corners=False),
  * modules/lawin.py:213-222, followed by ConvModule `cat`'s BatchNorm2d + Mish, lawin.py:101-105) of the coarse map x [B*hi*wi, C]:
  * the kernels read z = resize(x) through its four taps (the bits ss_bilinear_fwd would store), so the resized [B*ho*wo, C]
- * tensor is never written.  y, dy and dz are [B*ho*wo, C]; dz is the gradient of the resized map (ss_bilinear_bwd takes it to x). */
-int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo, int C, float eps, float momentum,
+ * tensor is never written.  y, dy and dz are [B*ho*wo, C]; dz is the gradient of the resized map (ss_bilinear_bwd takes it to x).
+ * bvec (NULL = none; x2 resize only): [B, C] fp32 added to the resized value of image b -- the image-pool branch of the concat in
+ * front of `cat` (modules/lawin.py:205-210) is constant over an image, so its share of the conv is one vector per image that
+ * commutes with the resize instead of E of the conv's 5E input columns; its gradient is the per-image column sum of dx. */
+int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi, int ho, int wo, int C, float eps, float momentum,
                    float* stats, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* workspace,
                    int64_t ws_bytes, hipStream_t stream);
-int ss_bn_apply_up(int dtype, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo, const float* stats,
+int ss_bn_apply_up(int dtype, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi, int ho, int wo, const float* stats,
                    const float* gamma, const float* beta, void* y, int64_t ldy, int C, int act, hipStream_t stream);
-int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo,
+int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi, int ho, int wo,
                  const float* stats, const float* gamma, const float* beta, int training, void* dz, int64_t ldo,
                  float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
 /* The x2 case (ho = 2 hi, wo = 2 wi) with the transpose of the resize folded into the second pass: returns
  * dx [B*hi*wi, C] = ss_bilinear_bwd(dz) and never writes dz (same weights; the sums run in another order). */
-int ss_bn_bwd_up2_dx(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, int B, int hi, int wi,
+int ss_bn_bwd_up2_dx(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi,
                      const float* stats, const float* gamma, const float* beta, int training, void* dx, int64_t ldo,
                      float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
 

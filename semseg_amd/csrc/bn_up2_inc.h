@@ -35,13 +35,17 @@ static inline Up2Geom up2_geom(int B, int hi, int wi, int C) {
 }
 template <typename T> struct Up2Row { RawN<T> a0, b0, a1, b1; };
 template <typename T> struct Up2 {
-    const T* base; int64_t rs, oA0, oB0, oA1, oB1; int hi; float l00, l01, l10, l11;
-    __device__ __forceinline__ void init(const T* x, int64_t ld, int hi_, int wi, int img, int j, int c) {
+    const T* base; int64_t rs, oA0, oB0, oA1, oB1; int hi; float l00, l01, l10, l11; float bv[UN];
+    // bvec: optional per-image, per-channel constant [B, C] added to the resized value (a term of the pre-resize map that is constant
+    // over an image commutes with the resize: the weights of every output pixel sum to one)
+    __device__ __forceinline__ void init(const T* x, int64_t ld, int hi_, int wi, int img, int j, int c, const float* bvec, int C) {
         const int jc = min(max(j, 0), wi - 1);
         const LinTap t0 = lin_tap(2 * jc, 0.5f, wi), t1 = lin_tap(2 * jc + 1, 0.5f, wi);
         hi = hi_; rs = (int64_t)wi * ld; base = x + (int64_t)img * hi * rs + c;
         oA0 = t0.i0 * ld; oB0 = t0.i1 * ld; oA1 = t1.i0 * ld; oB1 = t1.i1 * ld;
         l00 = t0.l0; l01 = t0.l1; l10 = t1.l0; l11 = t1.l1;
+#pragma unroll
+        for (int e = 0; e < UN; ++e) bv[e] = bvec ? bvec[(int64_t)img * C + c + e] : 0.f;
     }
     __device__ __forceinline__ void issue(int row, Up2Row<T>& r) const {
         const T* p = base + (int64_t)min(max(row, 0), hi - 1) * rs;
@@ -58,14 +62,14 @@ template <typename T> struct Up2 {
 // the two output rows of pair p from the lerped input rows p-1, p, p+1: z[r][col][e], rounded to T as ss_bilinear_fwd stores them
 template <typename T>
 __device__ __forceinline__ void up2_rows(int p, int hi, const float (&prev)[2][UN], const float (&cur)[2][UN], const float (&next)[2][UN],
-                                         float (&z)[2][2][UN]) {
+                                         float (&z)[2][2][UN], const float (&bv)[UN]) {
     const LinTap te = lin_tap(2 * p, 0.5f, hi), to = lin_tap(2 * p + 1, 0.5f, hi);
 #pragma unroll
     for (int col = 0; col < 2; ++col)
 #pragma unroll
         for (int e = 0; e < UN; ++e) {
-            z[0][col][e] = to_f(from_f<T>(fmaf(te.l1, cur[col][e], te.l0 * prev[col][e])));
-            z[1][col][e] = to_f(from_f<T>(fmaf(to.l1, next[col][e], to.l0 * cur[col][e])));
+            z[0][col][e] = to_f(from_f<T>(fmaf(te.l1, cur[col][e], te.l0 * prev[col][e]))) + bv[e];
+            z[1][col][e] = to_f(from_f<T>(fmaf(to.l1, next[col][e], to.l0 * cur[col][e]))) + bv[e];
         }
 }
 // Shared frame of the walker kernels.  body(p, z) runs once per row pair p in [ps, ps + 3 * ceil((pe - ps) / 3)): pairs >= pe are
@@ -81,7 +85,7 @@ __device__ __forceinline__ void up2_walk(const Up2<T>& U, int ps, int pe, F&& bo
         for (int i = 0; i < 3; ++i) {
             const int p = p0 + i;
             float z[2][2][UN];
-            up2_rows<T>(p, U.hi, H[i % 3], H[(i + 1) % 3], H[(i + 2) % 3], z);
+            up2_rows<T>(p, U.hi, H[i % 3], H[(i + 1) % 3], H[(i + 2) % 3], z, U.bv);
             body(p, z);
             U.hlerp(ring[i], H[i % 3]);                      // row p + 2 takes the slot of row p - 1
             U.issue(p + 5, ring[i]);
@@ -101,7 +105,7 @@ __device__ __forceinline__ Up2Tile up2_tile(int tile, const Up2Geom& g, int hi, 
 
 // partial[blockIdx.x][0][c] = sum (z - shift), [1] = sum (z - shift)^2 over this workgroup's tiles, shift = x[0][c]
 template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_up2_kernel(const T* __restrict__ x, int64_t ld, int B, int hi, int wi, int C, Up2Geom g,
+__global__ __launch_bounds__(256) void bn_stats_up2_kernel(const T* __restrict__ x, int64_t ld, const float* __restrict__ bvec, int B, int hi, int wi, int C, Up2Geom g,
                                                            float* __restrict__ partial) {
     __shared__ float red[256 * UN];
     const int tid = threadIdx.x, cl = tid % g.cpb, xs = tid / g.cpb;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void bn_stats_up2_kernel(const T* __restrict__
     const int ntiles = B * g.xtiles * g.ystrips;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const Up2Tile t = up2_tile(tile, g, hi, wi, xs);
-        Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c);
+        Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c, bvec, C);
         up2_walk<T>(U, t.ps, t.pe, [&](int p, const float (&z)[2][2][UN]) {
             const float live = (t.colok && cok && p < t.pe) ? 1.f : 0.f;
 #pragma unroll
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void bn_stats_up2_kernel(const T* __restrict__
 
 // y[2p + r][2j + col] = act(gamma * (z - mean) * rstd + beta)
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_apply_up2_kernel(const T* __restrict__ x, int64_t ld, int hi, int wi, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void bn_apply_up2_kernel(const T* __restrict__ x, int64_t ld, const float* __restrict__ bvec, int hi, int wi, const float* __restrict__ stats,
         const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, int64_t ldy, int C, Up2Geom g) {
     const int tid = threadIdx.x, cl = tid % g.cpb, xs = tid / g.cpb;
     const int chunk = blockIdx.y * g.cpb + cl;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_apply_up2_kernel(const T* __restrict__
       for (int e = 0; e < UN; ++e) { sc.v[e] = rs.v[e] * gm.v[e]; sh.v[e] = b.v[e] - mu.v[e] * sc.v[e]; } }
     const int wo = 2 * wi;
     T* yb = y + ((int64_t)t.img * 2 * hi * wo + 2 * t.j) * ldy + c;
-    Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c);
+    Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c, bvec, C);
     up2_walk<T>(U, t.ps, t.pe, [&](int p, const float (&z)[2][2][UN]) {
         if (p < t.pe) {
 #pragma unroll
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void bn_apply_up2_kernel(const T* __restrict__
 
 // backward over the resized map: PASS2 = false: partial sums of g and g * xhat; true: dz (the gradient of the resized map)
 template <typename T, int ACT, bool PASS2>
-__global__ __launch_bounds__(256) void bn_bwd_up2_kernel(const T* __restrict__ dy, int64_t ldd, const T* __restrict__ x, int64_t ld, int B, int hi, int wi,
+__global__ __launch_bounds__(256) void bn_bwd_up2_kernel(const T* __restrict__ dy, int64_t ldd, const T* __restrict__ x, int64_t ld, const float* __restrict__ bvec, int B, int hi, int wi,
         const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ coef,
         T* __restrict__ dz, int64_t ldo, float* __restrict__ partial, int C, Up2Geom g) {
     __shared__ float red[PASS2 ? 1 : 256 * UN];
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) void bn_bwd_up2_kernel(const T* __restrict__ d
         const T* db = dy + ob * ldd + c;
         T* zb = dz + ob * ldo + c;
         const bool live_t = t.colok && cok;
-        Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c);
+        Up2<T> U; U.init(x, ld, hi, wi, t.img, t.j, c, bvec, C);
         RawN<T> dn[2][2];                                    // dy of the pair about to be consumed
         { const int pp = min(t.ps, hi - 1);
 #pragma unroll
@@ -279,7 +283,7 @@ static inline Up2DxGeom up2dx_geom(int B, int hi, int wi, int C) {
     return g;
 }
 template <typename T, int ACT>
-__global__ __launch_bounds__(512) void bn_bwd_up2_dx_kernel(const T* __restrict__ dy, int64_t ldd, const T* __restrict__ x, int64_t ld, int hi, int wi,
+__global__ __launch_bounds__(512) void bn_bwd_up2_dx_kernel(const T* __restrict__ dy, int64_t ldd, const T* __restrict__ x, int64_t ld, const float* __restrict__ bvec, int hi, int wi,
         const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ coef,
         T* __restrict__ dx, int64_t ldo, int C, Up2DxGeom g) {
     __shared__ float ex[2][512][2][2][UN];                    // [buffer][thread][output row][output column][channel]
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(512) void bn_bwd_up2_dx_kernel(const T* __restrict_
     const int64_t ob = (int64_t)img * ho * wo + 2 * jc;
     const T* db = dy + ob * ldd + c;
     T* xb = dx + ((int64_t)img * hi * wi + jc) * ldo + c;
-    Up2<T> U; U.init(x, ld, hi, wi, img, j, c);
+    Up2<T> U; U.init(x, ld, hi, wi, img, j, c, bvec, C);
     RawN<T> dn[2][2];
     { const int pp = min(max(ps - 1, 0), hi - 1);
 #pragma unroll

@@ -368,11 +368,12 @@ static inline bool up2_ok(int hi, int wi, int ho, int wo) { return ho == 2 * hi 
 #define SS_UP_CHECK(name) \
     SS_CHECK(B > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && (int64_t)B * ho * wo < (1LL << 31) && (int64_t)B * hi * wi * ldx < (1LL << 40), \
              name ": bad resize geometry")
-extern "C" int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo, int C, float eps, float momentum,
+extern "C" int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi, int ho, int wo, int C, float eps, float momentum,
                               float* stats, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* workspace,
                               int64_t ws_bytes, hipStream_t stream) {
     SS_CHECK(x && stats && workspace && C > 0 && C % 8 == 0 && ldx >= C && ldx % 8 == 0 && aligned16(x), "ss_bn_stats_up: bad arguments (C=%d)", C);
     SS_UP_CHECK("ss_bn_stats_up");
+    SS_CHECK(!bvec || up2_ok(hi, wi, ho, wo), "ss_bn_stats_up: a per-image constant is only taken by the x2 resize");
     const int64_t rows = (int64_t)B * ho * wo;
     ColGeom g = col_geom(rows, C);
     SS_CHECK(ws_bytes >= (int64_t)g.nb * 2 * C * 4, "ss_bn_stats_up: workspace too small");
@@ -381,7 +382,7 @@ extern "C" int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, int B, int 
         using namespace w4;
         const Up2Geom u = up2_geom(B, hi, wi, C);
         nb = up2_blocks(u, B);
-        SS_DISPATCH(dtype, hipLaunchKernelGGL((bn_stats_up2_kernel<T>), dim3(nb, u.groups), dim3(256), 0, stream, (const T*)x, ldx, B, hi, wi, C, u, workspace));
+        SS_DISPATCH(dtype, hipLaunchKernelGGL((bn_stats_up2_kernel<T>), dim3(nb, u.groups), dim3(256), 0, stream, (const T*)x, ldx, bvec, B, hi, wi, C, u, workspace));
     } else SS_DISPATCH(dtype, {
         BnStatUpF<T> f{(const T*)x, ldx, up_geom(hi, wi, ho, wo)};
         hipLaunchKernelGGL((colreduce_partial_kernel<BnStatUpF<T>>), dim3(g.nb, 1), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
@@ -490,12 +491,13 @@ extern "C" int ss_bn_apply(int dtype, const void* z, int64_t ldz, const float* s
     return 0;
 }
 
-extern "C" int ss_bn_apply_up(int dtype, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo, const float* stats,
+extern "C" int ss_bn_apply_up(int dtype, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi, int ho, int wo, const float* stats,
                               const float* gamma, const float* beta, void* y, int64_t ldy, int C, int act, hipStream_t stream) {
     SS_CHECK(x && stats && gamma && beta && y && C > 0 && C % 8 == 0 && aligned16(x) && aligned16(y), "ss_bn_apply_up: bad arguments (C=%d)", C);
     SS_CHECK(ldx >= C && ldy >= C && ldx % 8 == 0 && ldy % 8 == 0, "ss_bn_apply_up: bad leading dimensions");
     SS_CHECK(act == 0 || act == 1, "ss_bn_apply_up: act must be 0 (none) or 1 (Mish)");
     SS_UP_CHECK("ss_bn_apply_up");
+    SS_CHECK(!bvec || up2_ok(hi, wi, ho, wo), "ss_bn_apply_up: a per-image constant is only taken by the x2 resize");
     const int64_t rows = (int64_t)B * ho * wo;
     ColGeom g = col_geom(rows, C);
     BnWalk w{g.cpb, g.rpb};
@@ -508,8 +510,8 @@ extern "C" int ss_bn_apply_up(int dtype, const void* x, int64_t ldx, int B, int 
         const Up2Geom u = up2_geom(B, hi, wi, C);
         dim3 grid((unsigned)(B * u.xtiles * u.ystrips), (unsigned)u.groups);
         SS_DISPATCH(dtype, {
-            if (act) hipLaunchKernelGGL((bn_apply_up2_kernel<T, 1>), grid, dim3(256), 0, stream, (const T*)x, ldx, hi, wi, stats, gamma, beta, (T*)y, ldy, C, u);
-            else hipLaunchKernelGGL((bn_apply_up2_kernel<T, 0>), grid, dim3(256), 0, stream, (const T*)x, ldx, hi, wi, stats, gamma, beta, (T*)y, ldy, C, u);
+            if (act) hipLaunchKernelGGL((bn_apply_up2_kernel<T, 1>), grid, dim3(256), 0, stream, (const T*)x, ldx, bvec, hi, wi, stats, gamma, beta, (T*)y, ldy, C, u);
+            else hipLaunchKernelGGL((bn_apply_up2_kernel<T, 0>), grid, dim3(256), 0, stream, (const T*)x, ldx, bvec, hi, wi, stats, gamma, beta, (T*)y, ldy, C, u);
         });
     } else SS_DISPATCH(dtype, { if (act) SS_BN_APPLY_UP(1); else SS_BN_APPLY_UP(0); });
 #undef SS_BN_APPLY_UP
@@ -649,7 +651,7 @@ extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, 
 }
 
 // the same with z = resize(x) read through its taps (no mask): dz is the gradient of the RESIZED map, [B*ho*wo, C]
-extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, int B, int hi, int wi, int ho, int wo,
+extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi, int ho, int wo,
                             const float* stats, const float* gamma, const float* beta, int training, void* dz, int64_t ldo,
                             float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream) {
     SS_CHECK(dy && x && stats && gamma && beta && dz && dgamma_dbeta && workspace && C > 0 && C % 8 == 0, "ss_bn_bwd_up: bad arguments");
@@ -657,6 +659,7 @@ extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* 
              "ss_bn_bwd_up: bad leading dimensions");
     SS_CHECK(act == 0 || act == 1, "ss_bn_bwd_up: act must be 0 (none) or 1 (Mish)");
     SS_UP_CHECK("ss_bn_bwd_up");
+    SS_CHECK(!bvec || up2_ok(hi, wi, ho, wo), "ss_bn_bwd_up: a per-image constant is only taken by the x2 resize");
     const int64_t rows = (int64_t)B * ho * wo;
     ColGeom g = col_geom(rows, C);
     SS_CHECK(ws_bytes >= ((int64_t)g.nb * 2 * C + 2 * C) * 4, "ss_bn_bwd_up: workspace too small");
@@ -672,7 +675,7 @@ extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* 
         const int nb = up2_blocks(u, B);
         dim3 g1((unsigned)nb, (unsigned)u.groups), g2((unsigned)(B * u.xtiles * u.ystrips), (unsigned)u.groups);
 #define SS_BN_BWD_UP2(ACT, P2, GRID) hipLaunchKernelGGL((bn_bwd_up2_kernel<T, ACT, P2>), GRID, dim3(256), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, \
-        B, hi, wi, stats, gamma, beta, coef, (T*)dz, ldo, workspace, C, u)
+        bvec, B, hi, wi, stats, gamma, beta, coef, (T*)dz, ldo, workspace, C, u)
         SS_DISPATCH(dtype, {
             if (act) SS_BN_BWD_UP2(1, false, g1); else SS_BN_BWD_UP2(0, false, g1);
             SS_LAUNCH_CHECK();
@@ -697,7 +700,7 @@ extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* 
 }
 
 // x2 only: pass 1 as ss_bn_bwd_up, pass 2 returns dx [B*hi*wi, C] = ss_bilinear_bwd(dz) directly (dz is never written)
-extern "C" int ss_bn_bwd_up2_dx(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, int B, int hi, int wi,
+extern "C" int ss_bn_bwd_up2_dx(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi,
                                 const float* stats, const float* gamma, const float* beta, int training, void* dx, int64_t ldo,
                                 float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream) {
     SS_CHECK(dy && x && stats && gamma && beta && dx && dgamma_dbeta && workspace && C > 0 && C % 8 == 0, "ss_bn_bwd_up2_dx: bad arguments");
@@ -716,16 +719,16 @@ extern "C" int ss_bn_bwd_up2_dx(int dtype, const void* dy, int64_t ldd, const vo
     const Up2DxGeom u2 = up2dx_geom(B, hi, wi, C);
     dim3 g1((unsigned)nb, (unsigned)u.groups), g2((unsigned)(B * u2.xtiles * u2.ystrips), (unsigned)u2.groups);
     SS_DISPATCH(dtype, {
-        if (act) hipLaunchKernelGGL((bn_bwd_up2_kernel<T, 1, false>), g1, dim3(256), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, B, hi, wi, stats, gamma, beta,
+        if (act) hipLaunchKernelGGL((bn_bwd_up2_kernel<T, 1, false>), g1, dim3(256), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, bvec, B, hi, wi, stats, gamma, beta,
                                     coef, (T*)nullptr, (int64_t)0, workspace, C, u);
-        else hipLaunchKernelGGL((bn_bwd_up2_kernel<T, 0, false>), g1, dim3(256), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, B, hi, wi, stats, gamma, beta,
+        else hipLaunchKernelGGL((bn_bwd_up2_kernel<T, 0, false>), g1, dim3(256), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, bvec, B, hi, wi, stats, gamma, beta,
                                 coef, (T*)nullptr, (int64_t)0, workspace, C, u);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, nb, C, rows, training, dgamma_dbeta, coef);
         SS_LAUNCH_CHECK();
-        if (act) hipLaunchKernelGGL((bn_bwd_up2_dx_kernel<T, 1>), g2, dim3(512), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, hi, wi, stats, gamma, beta, coef,
+        if (act) hipLaunchKernelGGL((bn_bwd_up2_dx_kernel<T, 1>), g2, dim3(512), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, bvec, hi, wi, stats, gamma, beta, coef,
                                     (T*)dx, ldo, C, u2);
-        else hipLaunchKernelGGL((bn_bwd_up2_dx_kernel<T, 0>), g2, dim3(512), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, hi, wi, stats, gamma, beta, coef,
+        else hipLaunchKernelGGL((bn_bwd_up2_dx_kernel<T, 0>), g2, dim3(512), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, bvec, hi, wi, stats, gamma, beta, coef,
                                 (T*)dx, ldo, C, u2);
     });
     SS_LAUNCH_CHECK();

@@ -108,7 +108,7 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
         U = ops.bilinear_fwd(gl, B, hw[lvl][0], hw[lvl][1], H8, W8, out=U, accumulate=U is not None)
     zf = ops.gemm_nt(cl[1], Wf[:, 2 * E:], res=U)
     stf = _bn_stats(zf, P, Bf, 'linear_fuse.bn', training)
-    cat5 = torch.empty((R8, 5 * E), dtype=T, device=dev)
+    cat5 = torch.empty((R8, 4 * E), dtype=T, device=dev)          # [feat, lawin_8, lawin_4, lawin_2]; the pooled branch is a vector per image
     feat = ops.bn_apply(zf, stf, P['linear_fuse.bn.weight'], P['linear_fuse.bn.bias'], act=1, out=cat5[:, :E])
     S.update(cl=cl, zf=zf, stf=stf, cat5=cat5)
 
@@ -126,19 +126,22 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     zp = ops.gemm_nt(gp, _conv_w(P['image_pool.1.conv.weight'], T))
     stp = _bn_stats(zp, P, Bf, 'image_pool.1.bn', training)
     ap = ops.bn_apply(zp, stp, P['image_pool.1.bn.weight'], P['image_pool.1.bn.bias'], act=1)
-    ops.bcast_rows(ap, cat5[:, 4 * E:], H8 * W8)
-    S.update(gp=gp, zp=zp, stp=stp)
+    S.update(gp=gp, zp=zp, stp=stp, ap=ap)
 
     # cat: 1x1 conv at S/8, bilinear x2, BN + Mish at S/4; low-level fuse; classifier
     # (the S/4 map z4 = resize(z8) is never written: the BatchNorm kernels read it through its bilinear taps, ss_bn_*_up)
-    z8 = ops.gemm_nt(cat5, _conv_w(P['cat.conv.weight'], T))
+    # The image-pool branch is constant over an image, so its E input columns of the conv are one vector per image (vb) that
+    # commutes with the resize and joins the map inside the BatchNorm kernels: the conv runs on 4E columns, not 5E.
+    Wc = _conv_w(P['cat.conv.weight'], T)
+    vb = ops.gemm_nt(ap, Wc[:, 4 * E:], out_f32=True)
+    z8 = ops.gemm_nt(cat5, Wc[:, :4 * E])
     if training:
         stc = ops.bn_stats_up(z8, B, H8, W8, H4, W4, 1e-5, 0.1, Bf['cat.bn.running_mean'], Bf['cat.bn.running_var'],
-                              Bf['cat.bn.num_batches_tracked'])
+                              Bf['cat.bn.num_batches_tracked'], bvec=vb)
     else:
         stc = ops.bn_eval_stats(Bf['cat.bn.running_mean'], Bf['cat.bn.running_var'])
     cat2 = torch.empty((R4, E + 48), dtype=T, device=dev)
-    ops.bn_apply_up(z8, B, H8, W8, H4, W4, stc, P['cat.bn.weight'], P['cat.bn.bias'], act=1, out=cat2[:, :E])
+    ops.bn_apply_up(z8, B, H8, W8, H4, W4, stc, P['cat.bn.weight'], P['cat.bn.bias'], act=1, out=cat2[:, :E], bvec=vb)
     ops.gemm_nt(t[0], w_fwd(P['linear_c1.proj.weight'], T), bias=P['linear_c1.proj.bias'], out=cat2[:, E:])
     zl = ops.gemm_nt(cat2, _conv_w(P['low_level_fuse.conv.weight'], T))
     stl = _bn_stats(zl, P, Bf, 'low_level_fuse.bn', training)
@@ -152,7 +155,7 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     else:
         fused = ops.bn_apply(zl, stl, P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'], act=1, mask=drop_mask, rows_per_image=rpi4)
         seg = ops.gemm_nt(fused, _conv_w(P['linear_pred.weight'], T), bias=P['linear_pred.bias'])
-    S.update(z8=z8, stc=stc, cat2=cat2, zl=zl, stl=stl, fused=fused, drop_mask=drop_mask, training=training)
+    S.update(z8=z8, vb=vb, stc=stc, cat2=cat2, zl=zl, stl=stl, fused=fused, drop_mask=drop_mask, training=training)
     return seg, S
 
 
@@ -187,13 +190,18 @@ def head_backward(P, S, dseg, E):
     dt = [ops.gemm_nt(dc1, w_bwd(P['linear_c1.proj.weight'], T)), None, None, None]
     # cat
     dz8, dgb = ops.bn_bwd_up_to_input(dcat2[:, :E], S['z8'], B, H8, W8, H4, W4, S['stc'], P['cat.bn.weight'], P['cat.bn.bias'], act=1,
-                                      training=training)
+                                      training=training, bvec=S['vb'])
     bn_grads('cat.bn', dgb)
-    G['cat.conv.weight'] = ops.gemm_tn(dz8, S['cat5'])
-    dcat5 = ops.gemm_nt(dz8, w_bwd(P['cat.conv.weight'], T))
+    Gc = torch.empty((E, 5 * E), dtype=torch.float32, device=dz8.device)
+    G['cat.conv.weight'] = Gc
+    ops.gemm_tn(dz8, S['cat5'], out=Gc[:, :4 * E])
+    Wct = w_bwd(P['cat.conv.weight'], T)                        # [5E, E]
+    dcat5 = ops.gemm_nt(dz8, Wct[:4 * E])
     feat = S['cat5'][:, :E]
-    # image-pool branch
-    dap = ops.cast(ops.colsum(dcat5[:, 4 * E:], groups=B), T)
+    # image-pool branch: the gradient of the per-image vector is the per-image column sum of dz8 (the resize preserves sums)
+    dvb = ops.cast(ops.colsum(dz8, groups=B), T)
+    ops.gemm_tn(dvb, S['ap'], out=Gc[:, 4 * E:])
+    dap = ops.gemm_nt(dvb, Wct[4 * E:])
     dzp, dgb = ops.bn_bwd(dap, S['zp'], S['stp'], P['image_pool.1.bn.weight'], P['image_pool.1.bn.bias'], act=1, training=training)
     bn_grads('image_pool.1.bn', dgb)
     G['image_pool.1.conv.weight'] = ops.gemm_tn(dzp, S['gp'])

@@ -441,38 +441,50 @@ def _up_args(x, B, hi, wi, name):
     return C, ldx
 
 
-def bn_stats_up(x, B, hi, wi, ho, wo, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt=None):
+def _bvec(bvec, B, C, hi, wi, ho, wo):
+    """optional per-image constant [B, C] fp32 added to the resized map (x2 resize only)"""
+    if bvec is None:
+        return
+    _f32(bvec, 'bvec', B * C)
+    if (ho, wo) != (2 * hi, 2 * wi):
+        raise ValueError('bn_*_up: bvec is only supported for the x2 resize')
+
+
+def bn_stats_up(x, B, hi, wi, ho, wo, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt=None, bvec=None):
     """bn_stats(bilinear_fwd(x, B, hi, wi, ho, wo)) without the resized tensor -> stats [2,C]."""
     dev = _dev(x)
     C, ldx = _up_args(x, B, hi, wi, 'bn_stats_up')
+    _bvec(bvec, B, C, hi, wi, ho, wo)
     _f32(running_mean, 'running_mean', C), _f32(running_var, 'running_var', C)
     if nbt is not None and nbt.dtype != torch.int64:
         raise ValueError('bn_stats_up: num_batches_tracked must be int64')
     stats = torch.empty((2, C), dtype=torch.float32, device=dev)
     ws = workspace(dev, COLRED_BLOCKS * 2 * C * 4)
-    check(lib().ss_bn_stats_up(dt(x), _p(x), ldx, B, hi, wi, ho, wo, C, eps, momentum, _p(stats), _p(running_mean), _p(running_var), _p(nbt),
+    check(lib().ss_bn_stats_up(dt(x), _p(x), ldx, _p(bvec), B, hi, wi, ho, wo, C, eps, momentum, _p(stats), _p(running_mean), _p(running_var), _p(nbt),
                                _p(ws), ws.numel(), _stream()))
     return stats
 
 
-def bn_apply_up(x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, out=None):
+def bn_apply_up(x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, out=None, bvec=None):
     """bn_apply(bilinear_fwd(x, ...), stats, gamma, beta, act) -> [B*ho*wo, C] (may be a channel slice of a wider buffer)."""
     dev = _dev(x)
     C, ldx = _up_args(x, B, hi, wi, 'bn_apply_up')
+    _bvec(bvec, B, C, hi, wi, ho, wo)
     _f32(stats, 'stats', 2 * C), _f32(gamma, 'gamma', C), _f32(beta, 'beta', C)
     if out is None:
         out = torch.empty((B * ho * wo, C), dtype=x.dtype, device=dev)
     ro, Co, ldy = _mat(out, 'out')
     if (ro, Co) != (B * ho * wo, C) or out.dtype != x.dtype:
         raise ValueError('bn_apply_up: bad out')
-    check(lib().ss_bn_apply_up(dt(x), _p(x), ldx, B, hi, wi, ho, wo, _p(stats), _p(gamma), _p(beta), _p(out), ldy, C, act, _stream()))
+    check(lib().ss_bn_apply_up(dt(x), _p(x), ldx, _p(bvec), B, hi, wi, ho, wo, _p(stats), _p(gamma), _p(beta), _p(out), ldy, C, act, _stream()))
     return out
 
 
-def bn_bwd_up(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True, out=None):
+def bn_bwd_up(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True, out=None, bvec=None):
     """bn_bwd(dy, bilinear_fwd(x, ...), ...) -> dz [B*ho*wo, C] (gradient of the RESIZED map), dgb [2,C]."""
     dev = _dev(x)
     C, ldx = _up_args(x, B, hi, wi, 'bn_bwd_up')
+    _bvec(bvec, B, C, hi, wi, ho, wo)
     rd, Cd, ldd = _mat(dy, 'dy')
     if (rd, Cd) != (B * ho * wo, C) or dy.dtype != x.dtype:
         raise ValueError('bn_bwd_up: dy mismatch')
@@ -484,18 +496,19 @@ def bn_bwd_up(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True
         raise ValueError('bn_bwd_up: bad out')
     dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
     ws = workspace(dev, (COLRED_BLOCKS * 2 * C + 2 * C) * 4)
-    check(lib().ss_bn_bwd_up(dt(x), _p(dy), ldd, _p(x), ldx, B, hi, wi, ho, wo, _p(stats), _p(gamma), _p(beta), int(training),
+    check(lib().ss_bn_bwd_up(dt(x), _p(dy), ldd, _p(x), ldx, _p(bvec), B, hi, wi, ho, wo, _p(stats), _p(gamma), _p(beta), int(training),
                              _p(out), ldo, _p(dgb), C, act, _p(ws), ws.numel(), _stream()))
     return out, dgb
 
 
-def bn_bwd_up_to_input(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True):
+def bn_bwd_up_to_input(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True, bvec=None):
     """bilinear_bwd(bn_bwd_up(...)[0]) -> dx [B*hi*wi, C], dgb [2,C]; for the x2 resize the gradient of the resized map is never written."""
     if (ho, wo) != (2 * hi, 2 * wi):
-        dz, dgb = bn_bwd_up(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=act, training=training)
+        dz, dgb = bn_bwd_up(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=act, training=training, bvec=bvec)
         return bilinear_bwd(dz, B, hi, wi, ho, wo), dgb
     dev = _dev(x)
     C, ldx = _up_args(x, B, hi, wi, 'bn_bwd_up_to_input')
+    _bvec(bvec, B, C, hi, wi, ho, wo)
     rd, Cd, ldd = _mat(dy, 'dy')
     if (rd, Cd) != (B * ho * wo, C) or dy.dtype != x.dtype:
         raise ValueError('bn_bwd_up_to_input: dy mismatch')
@@ -503,7 +516,7 @@ def bn_bwd_up_to_input(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, trai
     dx = torch.empty((B * hi * wi, C), dtype=x.dtype, device=dev)
     dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
     ws = workspace(dev, (COLRED_BLOCKS * 2 * C + 2 * C) * 4)
-    check(lib().ss_bn_bwd_up2_dx(dt(x), _p(dy), ldd, _p(x), ldx, B, hi, wi, _p(stats), _p(gamma), _p(beta), int(training),
+    check(lib().ss_bn_bwd_up2_dx(dt(x), _p(dy), ldd, _p(x), ldx, _p(bvec), B, hi, wi, _p(stats), _p(gamma), _p(beta), int(training),
                                  _p(dx), C, _p(dgb), C, act, _p(ws), ws.numel(), _stream()))
     return dx, dgb
 

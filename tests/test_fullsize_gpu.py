@@ -36,29 +36,6 @@ def test_full_size_eval_logits_are_batch_independent():
     assert float((both[0] - both[1]).abs().max()) > 1e-3 * scale           # the two images differ, so the check is not vacuous
 
 
-def test_full_size_training_step_reaches_every_parameter():
-    from semseg_amd.runtime import set_compute_dtype
-    from semseg_amd.detinit import det_input, det_labels
-    from semseg_amd.loss import OhemCrossEntropyLoss
-    net = _net().train()
-    x = det_input('full.x', (2, 3, 1024, 1024), 0, 1).cuda()
-    lab = det_labels('full.lab', (2, 1024, 1024), 6, cell=32).cuda()
-    set_compute_dtype(torch.bfloat16)
-    try:
-        out = net(x)
-        assert out.shape == (2, 6, 1024, 1024)
-        loss = OhemCrossEntropyLoss(0, 0.7, 0.1)(out, lab)
-        loss.backward()
-    finally:
-        set_compute_dtype(None)
-    assert torch.isfinite(loss)
-    dead = [n for n, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all() or float(p.grad.abs().max()) == 0.0]
-    # biases that sit directly before a training-mode BatchNorm have an analytically zero gradient
-    dead = [n for n in dead if not (n.endswith('.bias') and ('lawin' in n or 'conv' in n))]
-    assert not dead, dead[:8]
-
-
-# ---------------------------------------------------------------------------- configs[2]: DNet(ConvNeXt-T + Decoder(embed 256)), 1024^2, bf16
 def _dead(net):
     """parameters the step did not reach: no gradient, a non-finite one, or an all-zero one.  An all-zero gradient is legitimate for
     the parameters of ONE residual branch of an encoder block when DropPath dropped that branch for every image of the (2-image)
@@ -83,6 +60,29 @@ def _dead(net):
     return bad
 
 
+def test_full_size_training_step_reaches_every_parameter():
+    from semseg_amd.runtime import set_compute_dtype
+    from semseg_amd.detinit import det_input, det_labels
+    from semseg_amd.loss import OhemCrossEntropyLoss
+    net = _net().train()
+    x = det_input('full.x', (2, 3, 1024, 1024), 0, 1).cuda()
+    lab = det_labels('full.lab', (2, 1024, 1024), 6, cell=32).cuda()
+    set_compute_dtype(torch.bfloat16)
+    try:
+        out = net(x)
+        assert out.shape == (2, 6, 1024, 1024)
+        loss = OhemCrossEntropyLoss(0, 0.7, 0.1)(out, lab)
+        loss.backward()
+    finally:
+        set_compute_dtype(None)
+    assert torch.isfinite(loss)
+    dead = _dead(net)
+    # biases that sit directly before a training-mode BatchNorm have an analytically zero gradient
+    dead = [n for n in dead if not (n.endswith('.bias') and ('lawin' in n or 'conv' in n))]
+    assert not dead, dead[:8]
+
+
+# ---------------------------------------------------------------------------- configs[2]: DNet(ConvNeXt-T + Decoder(embed 256)), 1024^2, bf16
 def test_full_size_dnet_t_training_step_and_batch_independence():
     """ConvNeXt-T (dims up to 768, depth 9: never built by the small-fixture tests) + Decoder + terminator at 2 x 1024^2 in bf16:
     the probabilities of a training step sum to one at every pixel, the Dice step reaches every parameter, and eval-mode

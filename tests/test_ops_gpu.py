@@ -244,6 +244,36 @@ def test_batchnorm_of_bilinear_resize(ops, dtype, B, hi, wi, ho, wo, C, act):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,hi,wi,C,act', [(2, 8, 8, 64, 1), (3, 5, 7, 128, 0), (2, 16, 12, 512, 1)])
+def test_batchnorm_of_resize_with_per_image_constant(ops, dtype, B, hi, wi, C, act):
+    """bvec of ss_bn_*_up: BatchNorm (+ Mish) of resize(x) + v[image] (the image-pool branch of LawinHead's `cat` conv as one vector per
+    image, modules/lawin.py:205-222) against torch fp32; the gradient of v is the per-image column sum of the returned dx."""
+    ho, wo = 2 * hi, 2 * wi
+    x, v = rnd(B * hi * wi, C, scale=1.5) + 0.3, rnd(B, C, seed=11)
+    g, b, dy = 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2), rnd(B * ho * wo, C, seed=3)
+    xr, vr = q(x, dtype).requires_grad_(True), v.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    zi = F.interpolate(xr.view(B, hi, wi, C).permute(0, 3, 1, 2), size=(ho, wo), mode='bilinear', align_corners=False)
+    zq = zi + (zi.detach().to(dtype).float() - zi.detach()) + vr[:, :, None, None]
+    rm, rv = torch.zeros(C), torch.ones(C)
+    u = F.batch_norm(zq, rm, rv, gr, br, True, 0.1, 1e-5)
+    ref = (F.mish(u) if act else u).permute(0, 2, 3, 1).reshape(B * ho * wo, C)
+    ref.backward(q(dy, dtype))
+    xd, dyd, vd = dev(x, dtype), dev(dy, dtype), dev(v)
+    rm2, rv2 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    st = ops.bn_stats_up(xd, B, hi, wi, ho, wo, 1e-5, 0.1, rm2, rv2, None, bvec=vd)
+    assert rel(rm2, rm) < 1e-4 and rel(rv2, rv) < 1e-4
+    y = ops.bn_apply_up(xd, B, hi, wi, ho, wo, st, dev(g), dev(b), act, bvec=vd)
+    assert rel(y, ref) < _tol(dtype)
+    dz, dgb = ops.bn_bwd_up(dyd, xd, B, hi, wi, ho, wo, st, dev(g), dev(b), act, bvec=vd)
+    dx, dgb2 = ops.bn_bwd_up_to_input(dyd, xd, B, hi, wi, ho, wo, st, dev(g), dev(b), act, bvec=vd)
+    wtol = 1e-4 if dtype == torch.float32 else 2e-3
+    assert rel(dgb[0], gr.grad) < wtol and rel(dgb[1], br.grad) < wtol and rel(dgb2, dgb) < 1e-6
+    assert rel(dx, xr.grad) < _gtol(dtype) and rel(ops.bilinear_bwd(dz, B, hi, wi, ho, wo), xr.grad) < _gtol(dtype)
+    assert rel(ops.colsum(dx, groups=B), vr.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('rows,C,nc,masked', [(2000, 64, 6, True), (333, 128, 8, False), (4100, 512, 6, True), (70, 8, 2, False), (1026, 256, 3, True)])
 def test_batchnorm_mish_classifier(ops, dtype, rows, C, nc, masked):
     """ss_bn_apply_classify / ss_bn_bwd_classify (LawinHead tail, modules/lawin.py:101-105,227-228: BatchNorm2d + Mish + Dropout2d +
