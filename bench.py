@@ -101,17 +101,17 @@ def entry_work(name, a):
     # BatchNorm of a x2 bilinear resize without the resized tensor: the coarse map in (twice for the two backward passes), the
     # fine map out / the fine gradient in twice; the classifier-fused tail: z in (twice), logits / logit gradients, dz out
     if name == 'ss_bn_stats_up':
-        B, hi, wi, ho, wo, C = a[3:9]
+        B, hi, wi, ho, wo, C = a[4:10]
         return 'hbm', 1.0 * B * hi * wi * C * _sz(a[0])
     if name == 'ss_bn_apply_up':
-        B, hi, wi, ho, wo = a[3:8]
-        return 'hbm', 1.0 * B * (hi * wi + ho * wo) * a[13] * _sz(a[0])
+        B, hi, wi, ho, wo = a[4:9]
+        return 'hbm', 1.0 * B * (hi * wi + ho * wo) * a[14] * _sz(a[0])
     if name == 'ss_bn_bwd_up':
-        B, hi, wi, ho, wo = a[5:10]
-        return 'hbm', 1.0 * B * (2 * hi * wi + 3 * ho * wo) * a[17] * _sz(a[0])
+        B, hi, wi, ho, wo = a[6:11]
+        return 'hbm', 1.0 * B * (2 * hi * wi + 3 * ho * wo) * a[18] * _sz(a[0])
     if name == 'ss_bn_bwd_up2_dx':
-        B, hi, wi = a[5:8]
-        return 'hbm', 1.0 * B * (3 * hi * wi + 2 * 4 * hi * wi) * a[15] * _sz(a[0])
+        B, hi, wi = a[6:9]
+        return 'hbm', 1.0 * B * (3 * hi * wi + 2 * 4 * hi * wi) * a[16] * _sz(a[0])
     if name == 'ss_bn_apply_classify':
         return 'hbm', 1.0 * a[13] * (a[14] + a[10]) * _sz(a[0])
     if name == 'ss_bn_bwd_classify':
@@ -120,7 +120,7 @@ def entry_work(name, a):
         return 'hbm', 1.0 * a[3] * a[4] * a[5] * _sz(a[0])
     if name == 'ss_add':
         return 'hbm', 3.0 * a[4] * _sz(a[0])
-    if name == 'ss_bilinear_fwd':
+    if name in ('ss_bilinear_fwd', 'ss_bilinear_fwd_add'):
         B, hi, wi, ho, wo, C = a[5:11]
         return 'hbm', 1.0 * B * C * (hi * wi + ho * wo) * _sz(a[0])
     if name == 'ss_bilinear_bwd':
