@@ -76,6 +76,8 @@ def entry_work(name, a):
         return 'mfma', 2.0 * M * N * K
     if name == 'ss_gemm_nt':
         return 'mfma', 2.0 * a[8] * a[9] * a[10]
+    if name == 'ss_gemm_nt_bn_stats':
+        return 'mfma', 2.0 * a[7] * a[8] * a[9]
     if name in ('ss_gemm_tn', 'ss_gemm_tn_colsum'):
         return 'mfma', 2.0 * a[7] * a[8] * a[9]
     if name == 'ss_mit_attn_fwd':
@@ -164,6 +166,9 @@ def entry_bytes(name, a):
     if name == 'ss_gemm_nt':
         M, N, K = a[8:11]
         return (M * K + N * K + M * N * (2 if a[12] else 1)) * _sz(a[0])
+    if name == 'ss_gemm_nt_bn_stats':
+        M, N, K = a[7:10]
+        return (M * K + N * K + M * N * (2 if a[10] else 1)) * _sz(a[0])
     if name in ('ss_gemm_tn', 'ss_gemm_tn_colsum'):
         M, N, K = a[7:10]
         return (K * M + K * N) * _sz(a[0]) + M * N * 4
@@ -210,6 +215,10 @@ def shape_table(trace):
             sz = _sz(a[0])
             key = (name, M, N, K, 'res' if a[12] else '', 'f32out' if a[1] else '')
             byt = (M * K + N * K + M * N * (2 if a[12] else 1)) * sz
+        elif name == 'ss_gemm_nt_bn_stats':
+            M, N, K = a[7:10]
+            key = ('ss_gemm_nt', M, N, K, 'res' if a[10] else '', 'stats')
+            byt = (M * K + N * K + M * N * (2 if a[10] else 1)) * _sz(a[0])
         elif name in ('ss_gemm_tn', 'ss_gemm_tn_colsum'):
             M, N, K = a[7:10]
             key = ('ss_gemm_tn', M, N, K, 'cs' if name.endswith('colsum') else '', '')

@@ -93,6 +93,13 @@ int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, int64_t ldz
               const float* beta, const float* mask, int64_t rows_per_image, int training, void* dz, int64_t ldo,
               float* dgamma_dbeta, int64_t rows, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
+/* Bias-free 1x1 conv + the batch statistics of its output in one pass (conv -> BatchNorm2d of modules/lawin.py:49-54,97-105):
+ * C = A . B^T + res as ss_gemm_nt, stats / running buffers as ss_bn_stats(C).  On the bf16 tile kernels the column sums of the
+ * stored tile ride in the GEMM's copy-out; elsewhere the two calls run.  workspace >= max(cdiv(M,128), 1024) * 2 * N floats. */
+int ss_gemm_nt_bn_stats(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                        int64_t K, const void* res, int64_t ldr, float eps, float momentum, float* stats, float* running_mean,
+                        float* running_var, int64_t* num_batches_tracked, float* workspace, int64_t ws_bytes, hipStream_t stream);
+
 /* The same three steps for a BatchNorm whose input is a bilinear resize (tnf.interpolate(..., mode='bilinear', align_corners=False),
  * modules/lawin.py:213-222, followed by ConvModule `cat`'s BatchNorm2d + Mish, lawin.py:101-105) of the coarse map x [B*hi*wi, C]:
  * the kernels read z = resize(x) through its four taps (the bits ss_bilinear_fwd would store), so the resized [B*ho*wo, C]

@@ -130,15 +130,24 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(FastGemm p) {
     }
     nt_epilogue_dispatch<2, TN>(acc, p, smem, EP, m0, n0, wm * 64, wn * (BN / 2), li, lh);
     __syncthreads();
+    float sx[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sx[e] = 0.f; sq[e] = 0.f; }
 #pragma unroll
     for (int ps = 0; ps < BM / RPP; ++ps) {
         int row = ps * RPP + erow;
         if (m0 + row < p.M && ncol_ok) {
+            const bf16x8 v = *(const bf16x8*)(smem + row * EP + ech * 16);
             if (PATCH && (p.pm.side & 2))
-                *(bf16x8*)(C + patch_row(p.pm, m0 + row, p.ldc) + patch_col(p.pm, n0 + ech * 8)) = *(const bf16x8*)(smem + row * EP + ech * 16);
-            else nt_store_chunk(p, C, m0 + row, n0 + ech * 8, *(const bf16x8*)(smem + row * EP + ech * 16));
+                *(bf16x8*)(C + patch_row(p.pm, m0 + row, p.ldc) + patch_col(p.pm, n0 + ech * 8)) = v;
+            else nt_store_chunk(p, C, m0 + row, n0 + ech * 8, v);
+            if (!PATCH && p.stat_ws) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; sx[e] += f; sq[e] = fmaf(f, f, sq[e]); }
+            }
         }
     }
+    if (!PATCH && p.stat_ws) nt_tile_stats<BN, RPP, 256>(p, smem, sx, sq, erow, ech, m0 / BM, n0, tid);
 }
 
 // ------------------------------------------------------------------ TN (weight gradient)
@@ -278,6 +287,8 @@ static int big_enabled() {
     if (on < 0) { const char* e = getenv("SS_GEMM_BIG"); on = !(e && e[0] == '0'); }
     return on;
 }
+
+int64_t ss_fast_nt_stat_tiles(const FastGemm& p) { return cdiv(p.M, big_enabled() && ss_big_nt_ok(p) ? 256 : 128); }
 
 int ss_fast_nt_launch(FastGemm p, hipStream_t st) {
     if (big_enabled() && ss_big_nt_ok(p)) return ss_big_nt_launch(p, st);

@@ -139,12 +139,22 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(FastGemm p) {
         }
         return;
     }
+    float sx[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sx[e] = 0.f; sq[e] = 0.f; }
 #pragma unroll 4
     for (int ps = 0; ps < BM / RPP; ++ps) {
         int row = ps * RPP + erow;
-        if (m0 + row < p.M && ncol_ok && (!(p.dbg & 1) || acc[0][0][0] == 12345.f))
-            nt_store_chunk(p, C, m0 + row, n0 + ech * 8, *(const bf16x8*)(smem + row * EP + ech * 16));
+        if (m0 + row < p.M && ncol_ok && (!(p.dbg & 1) || acc[0][0][0] == 12345.f)) {
+            const bf16x8 v = *(const bf16x8*)(smem + row * EP + ech * 16);
+            nt_store_chunk(p, C, m0 + row, n0 + ech * 8, v);
+            if (p.stat_ws) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; sx[e] += f; sq[e] = fmaf(f, f, sq[e]); }
+            }
+        }
     }
+    if (p.stat_ws) nt_tile_stats<BN, RPP, 512>(p, smem, sx, sq, erow, ech, m0 / BM, n0, tid);
 }
 
 // LDS-DMA by hand for the persistent kernel.  hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of any LDS access once an
@@ -307,7 +317,7 @@ int ss_big_nt_launch(FastGemm p, hipStream_t st) {
     const int ntiles = (int)(p.ntn * cdiv(p.M, 256));
     // measured inside the training step (not in isolation): the persistent form wins 4-11 % where a CU walks >= 4 tiles of a
     // multi-column-tile output with a short k-loop, and loses up to 10 % on single-column-tile, one-tile-per-CU or long-K launches
-    if (mode == 2 && ntiles >= 4 * cu_count() && p.N >= 512 && p.K <= 1024) {
+    if (mode == 2 && ntiles >= 4 * cu_count() && p.N >= 512 && p.K <= 1024 && !p.stat_ws) {      // tile statistics: one tile per workgroup
         static int pfd = -1;                               // prefetch distance in k-tiles (SS_GEMM_PFD; measured: 0 .. 5 all within 1 %)
         if (pfd < 0) { const char* e = getenv("SS_GEMM_PFD"); pfd = e ? atoi(e) : 2; if (pfd < 0 || pfd > 16) pfd = 2; }
         hipLaunchKernelGGL(gemm_nt_bf16_256p_kernel, dim3((unsigned)cu_count()), dim3(512), 0, st, p, ntiles, pfd);

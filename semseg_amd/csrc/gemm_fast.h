@@ -33,7 +33,29 @@ struct FastGemm {
     // second product on the finished tile (gemm_nt_bf16_256_kernel, N == 256 only): out2[M, n2] = epilogue(A . B^T) . w2[n2, N]^T, n2 <= 32;
     // C is then not written (the classifier of a 1x1-conv head: the 256-channel activation never reaches memory)
     const bf16* w2; int64_t ldw2; int n2; bf16* out2; int64_t ldo2;
+    // NT, one tile per workgroup only: per-row-tile column sums of the stored (rounded) output, stat_ws[(m0 / BM) * 2 + k][N] with
+    // k = 0: sum, k = 1: sum of squares -- BatchNorm batch statistics of a 1x1 conv's output from the GEMM that produces it
+    float* stat_ws;
 };
+// Column statistics of the tile image during the copy-out: a thread keeps one 16-byte column chunk over its rows; the row lanes are
+// combined through LDS in a fixed order (bitwise reproducible).  Call from all threads after the copy-out loop.
+template <int BN, int RPP, int NT>
+__device__ __forceinline__ void nt_tile_stats(const FastGemm& p, char* smem, const float (&sx)[8], const float (&sq)[8], int erow, int ech,
+                                              int64_t tile_row, int n0, int tid) {
+    float* red = (float*)smem;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[((erow * BN) + ech * 8 + e) * 2] = sx[e]; red[((erow * BN) + ech * 8 + e) * 2 + 1] = sq[e]; }
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+        if (n0 + c < p.N) {
+            float s = 0.f, q = 0.f;
+            for (int r = 0; r < RPP; ++r) { s += red[((r * BN) + c) * 2]; q += red[((r * BN) + c) * 2 + 1]; }
+            float* dst = p.stat_ws + tile_row * 2 * p.N + n0 + c;
+            dst[0] = s; dst[p.N] = q;
+        }
+    }
+}
 
 // Copy-out of one 16-byte chunk of the NT kernels' LDS tile image: plain, or -- when C2 is set -- the pre-activation to C2 and
 // GELU of the (bf16-rounded) pre-activation to C, the very values a separate GELU pass over C2 would have produced.
@@ -51,6 +73,7 @@ __device__ __forceinline__ void nt_store_chunk(const FastGemm& p, bf16* C, int64
 bool ss_fast_nt_ok(const void* A, int64_t lda, const void* B, int64_t ldb, const void* C, int64_t ldc, int64_t M, int64_t N,
                    int64_t K, const void* res, int64_t ldr, const float* bias);
 int ss_fast_nt_launch(FastGemm p, hipStream_t st);
+int64_t ss_fast_nt_stat_tiles(const FastGemm& p);      // row tiles (= partial rows of stat_ws) of the kernel ss_fast_nt_launch picks
 bool ss_fast_tn_ok(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N);
 int ss_fast_tn_launch(FastGemm p, int nsplit, hipStream_t st);
 int ss_patch_nt_launch(FastGemm p, hipStream_t st);

@@ -4,6 +4,7 @@
 #include "common.h"
 #include "colreduce.h"
 #include "bilinear.h"
+#include "gemm_fast.h"
 
 // ------------------------------------------------------------------ LayerNorm
 // One row is handled by `lpr` lanes (power of two), NCH chunks of 8 channels per lane.
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (part != 0 || c >= C) return;
     s = 0.0; q = 0.0;
     for (int k = 0; k < 32; ++k) { s += sh[0][k][cx]; q += sh[1][k][cx]; }
-    const double shift = x_is_bf16 ? (double)(float)((const bf16*)x)[c] : (double)((const float*)x)[c];
+    const double shift = !x ? 0.0 : x_is_bf16 ? (double)(float)((const bf16*)x)[c] : (double)((const float*)x)[c];
     double md = s / (double)n, var = q / (double)n - md * md, mu = shift + md;
     if (var < 0) var = 0;
     stats[c] = (float)mu;
@@ -392,6 +393,41 @@ extern "C" int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, const float
                        stats, running_mean, running_var, num_batches_tracked, x, dtype == SS_BF16 ? 1 : 0);
     SS_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                          int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldr,
+                          const float* rowscale, int64_t rows_per_scale, int act, hipStream_t stream);
+// A bias-free 1x1 conv and the batch statistics of its output in one pass (ConvModule / conv_out of modules/lawin.py:49-54,97-105:
+// conv -> BatchNorm2d): C = A . B^T (+ res) as ss_gemm_nt, stats as ss_bn_stats(C).  On the bf16 tile kernels the column sums of the stored
+// (rounded) tile ride in the GEMM's copy-out -- one partial row per row tile, same fixed-order double-precision finalize -- and the
+// separate pass over C disappears (plain sums per 128 / 256 rows instead of sums shifted by row 0: the finalize subtracts in double).
+// Other shapes / fp32: the two calls.  workspace >= max(cdiv(M, 128), 1024) * 2 * N floats.
+extern "C" int ss_gemm_nt_bn_stats(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                                   int64_t K, const void* res, int64_t ldr, float eps, float momentum, float* stats, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float* workspace, int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(A && B && C && stats && workspace && M > 0 && N > 0 && K > 0 && N < (1 << 30) && lda >= K && ldb >= K && ldc >= N,
+             "ss_gemm_nt_bn_stats: bad arguments");
+    SS_CHECK(!res || ldr >= N, "ss_gemm_nt_bn_stats: bad ldr");
+    if (dtype == SS_BF16 && N % 8 == 0 && cdiv(M, 128) * cdiv(N, 64) < 2147483647LL) {
+        FastGemm f{};
+        f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = C; f.M = M; f.N = (int)N; f.K = K; f.lda = lda; f.ldb = ldb; f.ldc = ldc;
+        f.rows_per_scale = 1; f.k_per_split = K; f.res = (const bf16*)res; f.ldr = ldr;
+        if (!ss_skinny_nt_ok(f) && ss_fast_nt_ok(A, lda, B, ldb, C, ldc, M, N, K, res, ldr, nullptr)) {
+            f.stat_ws = workspace;
+            const int64_t nb = ss_fast_nt_stat_tiles(f);
+            SS_CHECK(ws_bytes >= nb * 2 * N * 4, "ss_gemm_nt_bn_stats: workspace too small");
+            int rc = ss_fast_nt_launch(f, stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(N, 8)), dim3(256), 0, stream, workspace, (int)nb, (int)N, M, eps, momentum,
+                               stats, running_mean, running_var, num_batches_tracked, (const void*)nullptr, 0);
+            SS_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    int rc = ss_gemm_nt(dtype, 0, A, lda, B, ldb, C, ldc, M, N, K, nullptr, res, ldr, nullptr, 0, 0, stream);
+    if (rc) return rc;
+    return ss_bn_stats(dtype, C, ldc, M, (int)N, eps, momentum, stats, running_mean, running_var, num_batches_tracked, workspace, ws_bytes, stream);
 }
 
 // eval mode: stats from running buffers

@@ -26,6 +26,13 @@ def _conv_w(w, dtype):
     return w_fwd(w, dtype)
 
 
+def _conv_bn_stats(a, w, P, Bf, prefix, training, res=None):
+    """bias-free 1x1 conv (+ res) followed by a BatchNorm's statistics: in training the column sums ride in the GEMM's copy-out"""
+    if training:
+        return ops.gemm_nt_bn_stats(a, w, res, 1e-5, 0.1, Bf[prefix + '.running_mean'], Bf[prefix + '.running_var'], Bf[prefix + '.num_batches_tracked'])
+    return ops.gemm_nt(a, w, res=res), ops.bn_eval_stats(Bf[prefix + '.running_mean'], Bf[prefix + '.running_var'])
+
+
 def _bn_stats(z, P, Bf, prefix, training):
     if training:
         return ops.bn_stats(z, 1e-5, 0.1, Bf[prefix + '.running_mean'], Bf[prefix + '.running_var'], Bf[prefix + '.num_batches_tracked'])
@@ -52,8 +59,7 @@ def branch_forward(P, Bf, qtok, G, B, H, W, r, heads, E, training, out=None):
     pg = ops.gemm_nt(ctx, wpg, bias=bpg)
     th = ops.gemm_nt(qtok, _conv_w(P['theta.weight'], T), bias=P['theta.bias'])
     y, lse = ops.lawin_attn_fwd(th, pg, B, H, W, heads)
-    z = ops.gemm_nt(y, _conv_w(P['conv_out.0.weight'], T))
-    st = _bn_stats(z, P, Bf, 'conv_out.1', training)
+    z, st = _conv_bn_stats(y, _conv_w(P['conv_out.0.weight'], T), P, Bf, 'conv_out.1', training)
     o = ops.bn_apply(z, st, P['conv_out.1.weight'], P['conv_out.1.bias'], act=0, res=qtok, out=out)
     return o, dict(G=G, Wm=Wm, ctx=ctx, pg=pg, th=th, y=y, lse=lse, z=z, st=st)
 
@@ -106,8 +112,7 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     for lvl, sl in ((2, slice(E, 2 * E)), (3, slice(0, E))):
         gl = ops.gemm_nt(cl[lvl], Wf[:, sl])
         U = ops.bilinear_fwd(gl, B, hw[lvl][0], hw[lvl][1], H8, W8, out=U, accumulate=U is not None)
-    zf = ops.gemm_nt(cl[1], Wf[:, 2 * E:], res=U)
-    stf = _bn_stats(zf, P, Bf, 'linear_fuse.bn', training)
+    zf, stf = _conv_bn_stats(cl[1], Wf[:, 2 * E:], P, Bf, 'linear_fuse.bn', training, res=U)
     cat5 = torch.empty((R8, 4 * E), dtype=T, device=dev)          # [feat, lawin_8, lawin_4, lawin_2]; the pooled branch is a vector per image
     feat = ops.bn_apply(zf, stf, P['linear_fuse.bn.weight'], P['linear_fuse.bn.bias'], act=1, out=cat5[:, :E])
     S.update(cl=cl, zf=zf, stf=stf, cat5=cat5)
@@ -143,8 +148,7 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     cat2 = torch.empty((R4, E + 48), dtype=T, device=dev)
     ops.bn_apply_up(z8, B, H8, W8, H4, W4, stc, P['cat.bn.weight'], P['cat.bn.bias'], act=1, out=cat2[:, :E], bvec=vb)
     ops.gemm_nt(t[0], w_fwd(P['linear_c1.proj.weight'], T), bias=P['linear_c1.proj.bias'], out=cat2[:, E:])
-    zl = ops.gemm_nt(cat2, _conv_w(P['low_level_fuse.conv.weight'], T))
-    stl = _bn_stats(zl, P, Bf, 'low_level_fuse.bn', training)
+    zl, stl = _conv_bn_stats(cat2, _conv_w(P['low_level_fuse.conv.weight'], T), P, Bf, 'low_level_fuse.bn', training)
     nc = P['linear_pred.weight'].shape[0]
     rpi4 = H4 * W4 if drop_mask is not None else 0
     if ops.bn_classify_ok(E, nc):

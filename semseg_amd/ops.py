@@ -194,6 +194,29 @@ def bn_stats(x, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt
     return stats
 
 
+def gemm_nt_bn_stats(a, b, res=None, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt=None):
+    """z = a @ b.T (+ res) and bn_stats(z) from one pass where the bf16 tile kernels take the shape -> (z, stats [2, N])."""
+    dev = _dev(a)
+    M, K, lda = _mat(a, 'a')
+    N, Kb, ldb = _mat(b, 'b')
+    if K != Kb or a.dtype != b.dtype:
+        raise ValueError(f'gemm_nt_bn_stats: a {tuple(a.shape)} {a.dtype} vs b {tuple(b.shape)} {b.dtype}')
+    ldr = 0
+    if res is not None:
+        Mr, Nr, ldr = _mat(res, 'res')
+        if (Mr, Nr) != (M, N) or res.dtype != a.dtype:
+            raise ValueError('gemm_nt_bn_stats: bad res')
+    _f32(running_mean, 'running_mean', N), _f32(running_var, 'running_var', N)
+    if nbt is not None and nbt.dtype != torch.int64:
+        raise ValueError('gemm_nt_bn_stats: num_batches_tracked must be int64')
+    z = torch.empty((M, N), dtype=a.dtype, device=dev)
+    stats = torch.empty((2, N), dtype=torch.float32, device=dev)
+    ws = workspace(dev, max(-(-M // 128), COLRED_BLOCKS) * 2 * N * 4)
+    check(lib().ss_gemm_nt_bn_stats(dt(a), _p(a), lda, _p(b), ldb, _p(z), N, M, N, K, _p(res), ldr, eps, momentum, _p(stats), _p(running_mean),
+                                    _p(running_var), _p(nbt), _p(ws), ws.numel(), _stream()))
+    return z, stats
+
+
 def bn_eval_stats(running_mean, running_var, eps=1e-5):
     C = running_mean.numel()
     _dev(running_mean)

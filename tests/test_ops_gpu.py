@@ -192,6 +192,27 @@ def test_batchnorm(ops, dtype, rows, C, act):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N,K,with_res', [(1000, 64, 64, False), (4099, 512, 560, False), (33000, 512, 256, True), (70000, 256, 512, False),
+                                            (131072 + 9, 512, 128, True), (300, 48, 32, False), (2, 512, 512, False)])
+def test_gemm_with_batchnorm_statistics(ops, dtype, M, N, K, with_res):
+    """ss_gemm_nt_bn_stats (conv -> BatchNorm2d of modules/lawin.py:49-54,97-105): the product is the one ss_gemm_nt gives, bit for bit, and
+    the statistics / running buffers agree with ss_bn_stats of that product (tile column sums from the GEMM's copy-out on the bf16 tile
+    kernels -- 128-row, 256-row and the shapes that would otherwise take the persistent kernel -- the two calls elsewhere)."""
+    a, b = rnd(M, K), rnd(N, K, seed=1) / math.sqrt(K)
+    res = dev(rnd(M, N, seed=3) + 0.5, dtype) if with_res else None
+    ad, bd = dev(a, dtype), dev(b, dtype)
+    z0 = ops.gemm_nt(ad, bd, res=res)
+    rm0, rv0, n0 = torch.zeros(N, device='cuda'), torch.ones(N, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda')
+    st0 = ops.bn_stats(z0, 1e-5, 0.1, rm0, rv0, n0)
+    rm1, rv1, n1 = torch.zeros(N, device='cuda'), torch.ones(N, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda')
+    z1, st1 = ops.gemm_nt_bn_stats(ad, bd, res, 1e-5, 0.1, rm1, rv1, n1)
+    assert torch.equal(z0, z1) and int(n1) == 1
+    assert rel(st1[0], st0[0]) < 1e-5 and rel(st1[1], st0[1]) < 1e-4 and rel(rm1, rm0) < 1e-5 and rel(rv1, rv0) < 1e-4
+    zf = z0.float().cpu().double()
+    assert rel(st1[0], zf.mean(0).float()) < 1e-5 and rel(st1[1], (zf.var(0, unbiased=False) + 1e-5).rsqrt().float()) < 1e-4
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,hi,wi,ho,wo,C,act', [(2, 8, 8, 16, 16, 64, 1), (1, 5, 7, 10, 14, 128, 0), (3, 6, 4, 13, 9, 48, 1), (2, 16, 16, 32, 32, 512, 1),
                                                  (1, 1, 3, 2, 6, 16, 0), (2, 50, 3, 100, 6, 1032, 1)])
 def test_batchnorm_of_bilinear_resize(ops, dtype, B, hi, wi, ho, wo, C, act):
