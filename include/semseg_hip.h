@@ -255,6 +255,17 @@ int ss_patch_pool_fwd(int dtype, const void* x, int64_t ldx, void* y, void* amax
 int ss_patch_pool_bwd(int dtype, const void* dy, const void* amax, void* dx, int B, int H, int W, int C, int ps, hipStream_t stream);
 /* window-ordered d(ctx) [B*nh*nw*64, C] -> dG_r (gather form, deterministic) */
 int ss_lawin_gather_bwd(int dtype, const void* dctx, float* dG, int B, int H, int W, int C, int r, hipStream_t stream);
+/* The branches' BatchNorm (no activation: BN_r(z) = s_r z + t_r) folded into the `cat` conv over [feat, feat + BN_8(z_8), feat + BN_4(z_4),
+ * feat + BN_2(z_2), pool] (modules/lawin.py:88-93,202-222): the conv runs over [feat | z_8 | z_4 | z_2] with Wout = [W_0 + W_1 + W_2 + W_3 |
+ * W_r diag(s_r)] (compute dtype, [E, 4E]) and the constant cconst = sum_r W_r t_r, so the normalised maps are never written.  W: the conv
+ * weight [E, >= 4E] fp32, stats_r = [2, E] (mean, rstd).  ss_lawin_cat_wgrad_fix turns G = dz^T [feat | z_8 | z_4 | z_2] (in place, the
+ * first 4E columns of [E, ldg]) into the gradient of W: dW_r = G_0 + G_r diag(s_r) + colsum(dz) (x) t_r, dvb = per-image column sums of dz [B, E]. */
+int ss_lawin_cat_fold(int dtype, const float* W, int64_t ldw, const float* stats8, const float* stats4, const float* stats2,
+                      const float* gamma8, const float* gamma4, const float* gamma2, const float* beta8, const float* beta4,
+                      const float* beta2, int E, void* Wout, float* cconst, hipStream_t stream);
+int ss_lawin_cat_wgrad_fix(float* G, int64_t ldg, const float* stats8, const float* stats4, const float* stats2,
+                           const float* gamma8, const float* gamma4, const float* gamma2, const float* beta8, const float* beta4,
+                           const float* beta2, const float* dvb, int B, int E, hipStream_t stream);
 /* LawinAttn.position_mixing (:44-46,62-69): out[w,p',c] = x[w,p',c] + sum_p Wm[head(c)][p'][p] x[w,p,c] + bm[head(c)][p'];
  * x gathered from G (xwin NULL) or read window-ordered (G NULL); transpose != 0 applies Wm^T without bias (backward).
  * Wm: [heads][64][64] fp32, bm: [heads][64] fp32; out: [windows*64, C].

@@ -596,3 +596,72 @@ extern "C" int ss_lawin_attn_bwd(int dtype, const void* theta, int64_t ldt, cons
                                                 (T*)dpg, g, inter, heads, stream); }));
     return rc;
 }
+
+// ------------------------------------------------------------------ the branches' BatchNorm folded into the `cat` conv
+// LawinHead concatenates [feat, feat + BN_8(z_8), feat + BN_4(z_4), feat + BN_2(z_2), pool] (modules/lawin.py:88-93,202-222) and runs
+// a 1x1 conv W = [W_0 | W_1 | W_2 | W_3 | W_p] over it.  The three BatchNorms have no activation, so BN_r(z) = s_r * z + t_r per
+// channel (s = gamma * rstd, t = beta - mean * s) and the conv over the concat equals
+//     (W_0 + W_1 + W_2 + W_3) . feat  +  sum_r (W_r diag(s_r)) . z_r  +  sum_r W_r t_r  +  W_p . pool
+// i.e. the same GEMM over [feat | z_8 | z_4 | z_2] with folded weights and a constant vector: the three normalise-and-add passes
+// over the S/8 map (and their outputs) disappear.  ss_lawin_cat_fold builds the folded weight [E, 4E] in the compute dtype and the
+// constant [E]; ss_lawin_cat_wgrad_fix turns the weight gradient of the folded GEMM, G' = dz^T [feat | z_8 | z_4 | z_2], into the
+// gradient of W:  dW_0 = G'_0,  dW_r = G'_0 + G'_r diag(s_r) + colsum(dz) (x) t_r.
+struct CatFoldArgs { const float* stats[3]; const float* gamma[3]; const float* beta[3]; };
+template <typename T>
+__global__ __launch_bounds__(256) void lawin_cat_fold_kernel(const float* __restrict__ W, int64_t ldw, CatFoldArgs a, int E, T* __restrict__ Wo,
+                                                             float* __restrict__ cconst) {
+    __shared__ float red[256];
+    const int n = blockIdx.x;
+    const float* w = W + (int64_t)n * ldw;
+    float c = 0.f;
+    for (int k = threadIdx.x; k < E; k += 256) {
+        float w0 = w[k];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float wr = w[(r + 1) * E + k];
+            const float sr = a.gamma[r][k] * a.stats[r][E + k], tr = a.beta[r][k] - a.stats[r][k] * sr;
+            Wo[(int64_t)n * 4 * E + (r + 1) * E + k] = from_f<T>(wr * sr);
+            c = fmaf(wr, tr, c);
+            w0 += wr;
+        }
+        Wo[(int64_t)n * 4 * E + k] = from_f<T>(w0);
+    }
+    red[threadIdx.x] = c; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) cconst[n] = red[0];
+}
+__global__ __launch_bounds__(256) void lawin_cat_wgrad_fix_kernel(float* __restrict__ G, int64_t ldg, CatFoldArgs a, const float* __restrict__ dvb, int B,
+                                                                  int E) {
+    const int n = blockIdx.x;
+    float cs = 0.f;
+    for (int b = 0; b < B; ++b) cs += dvb[(int64_t)b * E + n];
+    float* g = G + (int64_t)n * ldg;
+    for (int k = threadIdx.x; k < E; k += 256) {
+        const float g0 = g[k];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float sr = a.gamma[r][k] * a.stats[r][E + k], tr = a.beta[r][k] - a.stats[r][k] * sr;
+            g[(r + 1) * E + k] = fmaf(g[(r + 1) * E + k], sr, fmaf(cs, tr, g0));
+        }
+    }
+}
+extern "C" int ss_lawin_cat_fold(int dtype, const float* W, int64_t ldw, const float* stats8, const float* stats4, const float* stats2,
+                                 const float* gamma8, const float* gamma4, const float* gamma2, const float* beta8, const float* beta4,
+                                 const float* beta2, int E, void* Wout, float* cconst, hipStream_t stream) {
+    SS_CHECK(W && stats8 && stats4 && stats2 && gamma8 && gamma4 && gamma2 && beta8 && beta4 && beta2 && Wout && cconst && E > 0 && ldw >= 4 * (int64_t)E,
+             "ss_lawin_cat_fold: bad arguments");
+    CatFoldArgs a{{stats8, stats4, stats2}, {gamma8, gamma4, gamma2}, {beta8, beta4, beta2}};
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((lawin_cat_fold_kernel<T>), dim3(E), dim3(256), 0, stream, W, ldw, a, E, (T*)Wout, cconst));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ss_lawin_cat_wgrad_fix(float* G, int64_t ldg, const float* stats8, const float* stats4, const float* stats2,
+                                      const float* gamma8, const float* gamma4, const float* gamma2, const float* beta8, const float* beta4,
+                                      const float* beta2, const float* dvb, int B, int E, hipStream_t stream) {
+    SS_CHECK(G && stats8 && stats4 && stats2 && gamma8 && gamma4 && gamma2 && beta8 && beta4 && beta2 && dvb && B > 0 && E > 0 && ldg >= 4 * (int64_t)E,
+             "ss_lawin_cat_wgrad_fix: bad arguments");
+    CatFoldArgs a{{stats8, stats4, stats2}, {gamma8, gamma4, gamma2}, {beta8, beta4, beta2}};
+    hipLaunchKernelGGL(lawin_cat_wgrad_fix_kernel, dim3(E), dim3(256), 0, stream, G, ldg, a, dvb, B, E);
+    SS_LAUNCH_CHECK();
+    return 0;
+}

@@ -26,11 +26,12 @@ def _conv_w(w, dtype):
     return w_fwd(w, dtype)
 
 
-def _conv_bn_stats(a, w, P, Bf, prefix, training, res=None):
+def _conv_bn_stats(a, w, P, Bf, prefix, training, res=None, out=None):
     """bias-free 1x1 conv (+ res) followed by a BatchNorm's statistics: in training the column sums ride in the GEMM's copy-out"""
     if training:
-        return ops.gemm_nt_bn_stats(a, w, res, 1e-5, 0.1, Bf[prefix + '.running_mean'], Bf[prefix + '.running_var'], Bf[prefix + '.num_batches_tracked'])
-    return ops.gemm_nt(a, w, res=res), ops.bn_eval_stats(Bf[prefix + '.running_mean'], Bf[prefix + '.running_var'])
+        return ops.gemm_nt_bn_stats(a, w, res, 1e-5, 0.1, Bf[prefix + '.running_mean'], Bf[prefix + '.running_var'], Bf[prefix + '.num_batches_tracked'],
+                                    out=out)
+    return ops.gemm_nt(a, w, res=res, out=out), ops.bn_eval_stats(Bf[prefix + '.running_mean'], Bf[prefix + '.running_var'])
 
 
 def _bn_stats(z, P, Bf, prefix, training):
@@ -43,7 +44,7 @@ def _nchw_view(tok, B, H, W):
     return tok.view(B, H, W, -1).permute(0, 3, 1, 2)
 
 
-def branch_forward(P, Bf, qtok, G, B, H, W, r, heads, E, training, out=None):
+def branch_forward(P, Bf, qtok, G, B, H, W, r, heads, E, training, out=None, fold=False):
     """LawinAttn.forward (modules/lawin.py:57-94) on token matrices.  qtok: the query map [B*H*W, E] in image order (row stride may
     exceed E); G: the pooled context grid of ss_lawin_pool_fwd for ratio r -- for a stand-alone call on 8 x 8 windows (H = W = 8) the
     grid IS the window.  P / Bf: this LawinAttn's parameters / buffers by their own names.  -> (query + BN(conv_out(attention)), state)."""
@@ -59,8 +60,14 @@ def branch_forward(P, Bf, qtok, G, B, H, W, r, heads, E, training, out=None):
     pg = ops.gemm_nt(ctx, wpg, bias=bpg)
     th = ops.gemm_nt(qtok, _conv_w(P['theta.weight'], T), bias=P['theta.bias'])
     y, lse = ops.lawin_attn_fwd(th, pg, B, H, W, heads)
-    z, st = _conv_bn_stats(y, _conv_w(P['conv_out.0.weight'], T), P, Bf, 'conv_out.1', training)
-    o = ops.bn_apply(z, st, P['conv_out.1.weight'], P['conv_out.1.bias'], act=0, res=qtok, out=out)
+    if fold:
+        # LawinHead: conv_out's output z goes into the concat slice as it is; the BatchNorm (affine per channel, no activation) and
+        # the residual are folded into the weights of the `cat` conv that reads the concat (ops.lawin_cat_fold)
+        z, st = _conv_bn_stats(y, _conv_w(P['conv_out.0.weight'], T), P, Bf, 'conv_out.1', training, out=out)
+        o = None
+    else:
+        z, st = _conv_bn_stats(y, _conv_w(P['conv_out.0.weight'], T), P, Bf, 'conv_out.1', training)
+        o = ops.bn_apply(z, st, P['conv_out.1.weight'], P['conv_out.1.bias'], act=0, res=qtok, out=out)
     return o, dict(G=G, Wm=Wm, ctx=ctx, pg=pg, th=th, y=y, lse=lse, z=z, st=st)
 
 
@@ -89,6 +96,12 @@ def branch_backward(P, br, dout, qtok, acc, B, H, W, r, heads, E, training):
     return acc, ops.lawin_gather_bwd(dctx, B, H, W, r), G
 
 
+def _cat_fold_operands(P, brs):
+    """(stats, gammas, betas) of the three branch BatchNorms in concat order (r = 8, 4, 2)"""
+    names = [f'lawin_{r}.conv_out.1' for r, _ in LAWIN_BRANCHES]
+    return [br['st'] for br in brs], [P[n + '.weight'].detach() for n in names], [P[n + '.bias'].detach() for n in names]
+
+
 def head_forward(P, Bf, feats, E, training, drop_mask):
     """feats: 4 NCHW-shaped maps (S/4..S/32).  -> logits tokens [B*H4*W4, nc], saved state."""
     T = compute_dtype_for(feats[0])
@@ -113,7 +126,7 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
         gl = ops.gemm_nt(cl[lvl], Wf[:, sl])
         U = ops.bilinear_fwd(gl, B, hw[lvl][0], hw[lvl][1], H8, W8, out=U, accumulate=U is not None)
     zf, stf = _conv_bn_stats(cl[1], Wf[:, 2 * E:], P, Bf, 'linear_fuse.bn', training, res=U)
-    cat5 = torch.empty((R8, 4 * E), dtype=T, device=dev)          # [feat, lawin_8, lawin_4, lawin_2]; the pooled branch is a vector per image
+    cat5 = torch.empty((R8, 4 * E), dtype=T, device=dev)          # [feat, z_8, z_4, z_2] (conv_out outputs); the pooled branch is a vector per image
     feat = ops.bn_apply(zf, stf, P['linear_fuse.bn.weight'], P['linear_fuse.bn.bias'], act=1, out=cat5[:, :E])
     S.update(cl=cl, zf=zf, stf=stf, cat5=cat5)
 
@@ -122,7 +135,7 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     for k, (r, heads) in enumerate(LAWIN_BRANCHES):
         G, amax = ops.lawin_pool_fwd(feat, B, H8, W8, r)
         _, br = branch_forward(_sub(P, f'lawin_{r}.'), _sub(Bf, f'lawin_{r}.'), feat, G, B, H8, W8, r, heads, E, training,
-                               out=cat5[:, (k + 1) * E:(k + 2) * E])
+                               out=cat5[:, (k + 1) * E:(k + 2) * E], fold=True)
         br['amax'] = amax
         S['br'].append(br)
 
@@ -138,8 +151,10 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     # The image-pool branch is constant over an image, so its E input columns of the conv are one vector per image (vb) that
     # commutes with the resize and joins the map inside the BatchNorm kernels: the conv runs on 4E columns, not 5E.
     Wc = _conv_w(P['cat.conv.weight'], T)
-    vb = ops.gemm_nt(ap, Wc[:, 4 * E:], out_f32=True)
-    z8 = ops.gemm_nt(cat5, Wc[:, :4 * E])
+    fold = _cat_fold_operands(P, S['br'])
+    Wcf, cconst = ops.lawin_cat_fold(P['cat.conv.weight'].detach().view(E, 5 * E), *fold, E, T)
+    vb = ops.gemm_nt(ap, Wc[:, 4 * E:], bias=cconst, out_f32=True)
+    z8 = ops.gemm_nt(cat5, Wcf)
     if training:
         stc = ops.bn_stats_up(z8, B, H8, W8, H4, W4, 1e-5, 0.1, Bf['cat.bn.running_mean'], Bf['cat.bn.running_var'],
                               Bf['cat.bn.num_batches_tracked'], bvec=vb)
@@ -200,10 +215,12 @@ def head_backward(P, S, dseg, E):
     G['cat.conv.weight'] = Gc
     ops.gemm_tn(dz8, S['cat5'], out=Gc[:, :4 * E])
     Wct = w_bwd(P['cat.conv.weight'], T)                        # [5E, E]
-    dcat5 = ops.gemm_nt(dz8, Wct[:4 * E])
+    dcat5 = ops.gemm_nt(dz8, Wct[:4 * E])                       # gradients of the concat's slices [feat, feat + BN(z_r)], as the reference has them
     feat = S['cat5'][:, :E]
     # image-pool branch: the gradient of the per-image vector is the per-image column sum of dz8 (the resize preserves sums)
-    dvb = ops.cast(ops.colsum(dz8, groups=B), T)
+    dvb32 = ops.colsum(dz8, groups=B)
+    ops.lawin_cat_wgrad_fix(Gc, *_cat_fold_operands(P, S['br']), dvb32, B, E)
+    dvb = ops.cast(dvb32, T)
     ops.gemm_tn(dvb, S['ap'], out=Gc[:, 4 * E:])
     dap = ops.gemm_nt(dvb, Wct[4 * E:])
     dzp, dgb = ops.bn_bwd(dap, S['zp'], S['stp'], P['image_pool.1.bn.weight'], P['image_pool.1.bn.bias'], act=1, training=training)

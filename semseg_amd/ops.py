@@ -194,7 +194,7 @@ def bn_stats(x, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt
     return stats
 
 
-def gemm_nt_bn_stats(a, b, res=None, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt=None):
+def gemm_nt_bn_stats(a, b, res=None, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt=None, out=None):
     """z = a @ b.T (+ res) and bn_stats(z) from one pass where the bf16 tile kernels take the shape -> (z, stats [2, N])."""
     dev = _dev(a)
     M, K, lda = _mat(a, 'a')
@@ -209,10 +209,13 @@ def gemm_nt_bn_stats(a, b, res=None, eps=1e-5, momentum=0.1, running_mean=None, 
     _f32(running_mean, 'running_mean', N), _f32(running_var, 'running_var', N)
     if nbt is not None and nbt.dtype != torch.int64:
         raise ValueError('gemm_nt_bn_stats: num_batches_tracked must be int64')
-    z = torch.empty((M, N), dtype=a.dtype, device=dev)
+    z = torch.empty((M, N), dtype=a.dtype, device=dev) if out is None else out
+    Mo, No, ldc = _mat(z, 'out')
+    if (Mo, No) != (M, N) or z.dtype != a.dtype:
+        raise ValueError('gemm_nt_bn_stats: bad out')
     stats = torch.empty((2, N), dtype=torch.float32, device=dev)
     ws = workspace(dev, max(-(-M // 128), COLRED_BLOCKS) * 2 * N * 4)
-    check(lib().ss_gemm_nt_bn_stats(dt(a), _p(a), lda, _p(b), ldb, _p(z), N, M, N, K, _p(res), ldr, eps, momentum, _p(stats), _p(running_mean),
+    check(lib().ss_gemm_nt_bn_stats(dt(a), _p(a), lda, _p(b), ldb, _p(z), ldc, M, N, K, _p(res), ldr, eps, momentum, _p(stats), _p(running_mean),
                                     _p(running_var), _p(nbt), _p(ws), ws.numel(), _stream()))
     return z, stats
 
@@ -542,6 +545,35 @@ def bn_bwd_up_to_input(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, trai
     check(lib().ss_bn_bwd_up2_dx(dt(x), _p(dy), ldd, _p(x), ldx, _p(bvec), B, hi, wi, _p(stats), _p(gamma), _p(beta), int(training),
                                  _p(dx), C, _p(dgb), C, act, _p(ws), ws.numel(), _stream()))
     return dx, dgb
+
+
+# ------------------------------------------------------------------ LawinHead: branch BatchNorms folded into the `cat` conv
+def lawin_cat_fold(W, stats, gammas, betas, E, dtype):
+    """W: cat conv weight [E, >= 4E] fp32 (row stride = W.stride(0)); stats / gammas / betas: three each (branches r = 8, 4, 2).
+    -> (folded weight [E, 4E] in dtype, constant [E] fp32)."""
+    dev = _dev(W)
+    rows, cols, ldw = _mat(W, 'W')
+    if W.dtype != torch.float32 or rows != E or cols < 4 * E:
+        raise ValueError('lawin_cat_fold: W must be fp32 [E, >= 4E]')
+    for t in list(stats) + list(gammas) + list(betas):
+        _f32(t, 'stats/gamma/beta')
+    Wo = torch.empty((E, 4 * E), dtype=dtype, device=dev)
+    cc = torch.empty(E, dtype=torch.float32, device=dev)
+    check(lib().ss_lawin_cat_fold(_DT[dtype], _p(W), ldw, *[_p(t) for t in stats], *[_p(t) for t in gammas], *[_p(t) for t in betas], E,
+                                  _p(Wo), _p(cc), _stream()))
+    return Wo, cc
+
+
+def lawin_cat_wgrad_fix(G, stats, gammas, betas, dvb, B, E):
+    """in place on the first 4E columns of G [E, ld]: gradient of the folded GEMM's weight -> gradient of the cat conv weight."""
+    _dev(G)
+    rows, cols, ldg = _mat(G, 'G')
+    if G.dtype != torch.float32 or rows != E or cols < 4 * E:
+        raise ValueError('lawin_cat_wgrad_fix: G must be fp32 [E, >= 4E]')
+    _f32(dvb, 'dvb', B * E)
+    check(lib().ss_lawin_cat_wgrad_fix(_p(G), ldg, *[_p(t) for t in stats], *[_p(t) for t in gammas], *[_p(t) for t in betas], _p(dvb), B, E,
+                                       _stream()))
+    return G
 
 
 # ------------------------------------------------------------------ BatchNorm + Mish + Dropout2d + narrow classifier in one pass
