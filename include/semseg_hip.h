@@ -246,7 +246,8 @@ int ss_lawin_pool_fwd(int dtype, const void* feat, int64_t ld, void* G, void* am
                       hipStream_t stream);
 /* d(feat) = base + sum over r of the avg and arg-max shares of dG_r (fp32 [B,gh,gw,C]) */
 int ss_lawin_pool_bwd(int dtype, const float* dG8, const float* dG4, const float* dG2, const void* amax8, const void* amax4,
-                      const void* amax2, const void* base, int64_t ldb, void* dfeat, int64_t ldo, int B, int H, int W, int C,
+                      const void* amax2, const void* base, int64_t ldb, const float* bvec /* optional [B, C]: added per image */,
+                      void* dfeat, int64_t ldo, int B, int H, int W, int C,
                       hipStream_t stream);
 /* Stand-alone PatchEmbed.forward (modules/lawin.py:27-35): y [B,ceil(H/ps),ceil(W/ps),C] = 0.5*(max_pool + avg_pool) over ps x ps cells of
  * x [B,H,W,C] (row stride ldx), zeros beyond the right / bottom edge taking part as F.pad's do; amax: uint8 arg-max position per cell.
@@ -262,7 +263,8 @@ int ss_lawin_gather_bwd(int dtype, const void* dctx, float* dG, int B, int H, in
  * first 4E columns of [E, ldg]) into the gradient of W: dW_r = G_0 + G_r diag(s_r) + colsum(dz) (x) t_r, dvb = per-image column sums of dz [B, E]. */
 int ss_lawin_cat_fold(int dtype, const float* W, int64_t ldw, const float* stats8, const float* stats4, const float* stats2,
                       const float* gamma8, const float* gamma4, const float* gamma2, const float* beta8, const float* beta4,
-                      const float* beta2, int E, void* Wout, float* cconst, hipStream_t stream);
+                      const float* beta2, int E, void* Wout, void* Wt /* [4E, E]: (W_0+W_1+W_2+W_3)^T, W_1^T, W_2^T, W_3^T */, float* cconst,
+                      hipStream_t stream);
 int ss_lawin_cat_wgrad_fix(float* G, int64_t ldg, const float* stats8, const float* stats4, const float* stats2,
                            const float* gamma8, const float* gamma4, const float* gamma2, const float* beta8, const float* beta4,
                            const float* beta2, const float* dvb, int B, int E, hipStream_t stream);

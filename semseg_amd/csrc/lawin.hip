@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void lawin_pool_fwd_kernel(const T* __restrict
 // d(feat)[b,y,x,:] = base + sum_r ( 0.5/r^2 * dG_r[cell] + 0.5 * dG_r[cell] * [amax_r[cell] == position] )
 struct PoolBwdArgs { const float* dG[3]; const unsigned char* amax[3]; WinGeom g[3]; };
 template <typename T>
-__global__ __launch_bounds__(256) void lawin_pool_bwd_kernel(PoolBwdArgs a, const T* __restrict__ base, int64_t ldb, T* __restrict__ dfeat,
-                                                             int64_t ldo, int C) {
+__global__ __launch_bounds__(256) void lawin_pool_bwd_kernel(PoolBwdArgs a, const T* __restrict__ base, int64_t ldb, const float* __restrict__ bvec,
+                                                             T* __restrict__ dfeat, int64_t ldo, int C) {
     const int chunks = C / 8;
     const WinGeom g0 = a.g[0];
     const int64_t total = (int64_t)g0.B * g0.H * g0.W * chunks;
@@ -71,6 +71,9 @@ __global__ __launch_bounds__(256) void lawin_pool_bwd_kernel(PoolBwdArgs a, cons
         const int c = (int)(i % chunks) * 8; int64_t p = i / chunks;
         const int x = (int)(p % g0.W); int64_t q = p / g0.W; const int y = (int)(q % g0.H); const int64_t b = q / g0.H;
         F8 acc = base ? load8(base + p * ldb + c) : zero8();
+        if (bvec) { const F8 bv = load8(bvec + b * C + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc.v[e] += bv.v[e]; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const WinGeom g = a.g[k];
@@ -419,7 +422,7 @@ extern "C" int ss_lawin_pool_fwd(int dtype, const void* feat, int64_t ld, void* 
 }
 
 extern "C" int ss_lawin_pool_bwd(int dtype, const float* dG8, const float* dG4, const float* dG2, const void* amax8, const void* amax4,
-                                 const void* amax2, const void* base, int64_t ldb, void* dfeat, int64_t ldo, int B, int H, int W, int C,
+                                 const void* amax2, const void* base, int64_t ldb, const float* bvec, void* dfeat, int64_t ldo, int B, int H, int W, int C,
                                  hipStream_t stream) {
     SS_CHECK(dG8 && dG4 && dG2 && amax8 && amax4 && amax2 && dfeat && ldo >= C && ldo % 8 == 0 && (!base || (ldb >= C && ldb % 8 == 0)),
              "ss_lawin_pool_bwd: bad arguments");
@@ -429,7 +432,7 @@ extern "C" int ss_lawin_pool_bwd(int dtype, const float* dG8, const float* dG4, 
     a.amax[0] = (const unsigned char*)amax8; a.amax[1] = (const unsigned char*)amax4; a.amax[2] = (const unsigned char*)amax2;
     a.g[0] = win_geom(B, H, W, 8); a.g[1] = win_geom(B, H, W, 4); a.g[2] = win_geom(B, H, W, 2);
     SS_DISPATCH(dtype, hipLaunchKernelGGL((lawin_pool_bwd_kernel<T>), dim3(nblk((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, a,
-                                          (const T*)base, ldb, (T*)dfeat, ldo, C));
+                                          (const T*)base, ldb, bvec, (T*)dfeat, ldo, C));
     SS_LAUNCH_CHECK();
     return 0;
 }
@@ -603,13 +606,14 @@ extern "C" int ss_lawin_attn_bwd(int dtype, const void* theta, int64_t ldt, cons
 // channel (s = gamma * rstd, t = beta - mean * s) and the conv over the concat equals
 //     (W_0 + W_1 + W_2 + W_3) . feat  +  sum_r (W_r diag(s_r)) . z_r  +  sum_r W_r t_r  +  W_p . pool
 // i.e. the same GEMM over [feat | z_8 | z_4 | z_2] with folded weights and a constant vector: the three normalise-and-add passes
-// over the S/8 map (and their outputs) disappear.  ss_lawin_cat_fold builds the folded weight [E, 4E] in the compute dtype and the
-// constant [E]; ss_lawin_cat_wgrad_fix turns the weight gradient of the folded GEMM, G' = dz^T [feat | z_8 | z_4 | z_2], into the
+// over the S/8 map (and their outputs) disappear.  ss_lawin_cat_fold builds the folded weight [E, 4E] in the compute dtype, the
+// constant [E] and Wt = [(W_0 + W_1 + W_2 + W_3)^T ; W_1^T ; W_2^T ; W_3^T] ([4E, E]: the data-gradient GEMM over it leaves the SUM of the four
+// slice gradients -- the gradient fan-in on feat -- in the first E columns, beside the three slice gradients the BatchNorm backward needs); ss_lawin_cat_wgrad_fix turns the weight gradient of the folded GEMM, G' = dz^T [feat | z_8 | z_4 | z_2], into the
 // gradient of W:  dW_0 = G'_0,  dW_r = G'_0 + G'_r diag(s_r) + colsum(dz) (x) t_r.
 struct CatFoldArgs { const float* stats[3]; const float* gamma[3]; const float* beta[3]; };
 template <typename T>
 __global__ __launch_bounds__(256) void lawin_cat_fold_kernel(const float* __restrict__ W, int64_t ldw, CatFoldArgs a, int E, T* __restrict__ Wo,
-                                                             float* __restrict__ cconst) {
+                                                             T* __restrict__ Wt, float* __restrict__ cconst) {
     __shared__ float red[256];
     const int n = blockIdx.x;
     const float* w = W + (int64_t)n * ldw;
@@ -621,10 +625,12 @@ __global__ __launch_bounds__(256) void lawin_cat_fold_kernel(const float* __rest
             const float wr = w[(r + 1) * E + k];
             const float sr = a.gamma[r][k] * a.stats[r][E + k], tr = a.beta[r][k] - a.stats[r][k] * sr;
             Wo[(int64_t)n * 4 * E + (r + 1) * E + k] = from_f<T>(wr * sr);
+            Wt[((int64_t)(r + 1) * E + k) * E + n] = from_f<T>(wr);
             c = fmaf(wr, tr, c);
             w0 += wr;
         }
         Wo[(int64_t)n * 4 * E + k] = from_f<T>(w0);
+        Wt[(int64_t)k * E + n] = from_f<T>(w0);
     }
     red[threadIdx.x] = c; __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
@@ -647,11 +653,11 @@ __global__ __launch_bounds__(256) void lawin_cat_wgrad_fix_kernel(float* __restr
 }
 extern "C" int ss_lawin_cat_fold(int dtype, const float* W, int64_t ldw, const float* stats8, const float* stats4, const float* stats2,
                                  const float* gamma8, const float* gamma4, const float* gamma2, const float* beta8, const float* beta4,
-                                 const float* beta2, int E, void* Wout, float* cconst, hipStream_t stream) {
-    SS_CHECK(W && stats8 && stats4 && stats2 && gamma8 && gamma4 && gamma2 && beta8 && beta4 && beta2 && Wout && cconst && E > 0 && ldw >= 4 * (int64_t)E,
+                                 const float* beta2, int E, void* Wout, void* Wt, float* cconst, hipStream_t stream) {
+    SS_CHECK(W && stats8 && stats4 && stats2 && gamma8 && gamma4 && gamma2 && beta8 && beta4 && beta2 && Wout && Wt && cconst && E > 0 && ldw >= 4 * (int64_t)E,
              "ss_lawin_cat_fold: bad arguments");
     CatFoldArgs a{{stats8, stats4, stats2}, {gamma8, gamma4, gamma2}, {beta8, beta4, beta2}};
-    SS_DISPATCH(dtype, hipLaunchKernelGGL((lawin_cat_fold_kernel<T>), dim3(E), dim3(256), 0, stream, W, ldw, a, E, (T*)Wout, cconst));
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((lawin_cat_fold_kernel<T>), dim3(E), dim3(256), 0, stream, W, ldw, a, E, (T*)Wout, (T*)Wt, cconst));
     SS_LAUNCH_CHECK();
     return 0;
 }

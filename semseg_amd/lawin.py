@@ -152,7 +152,7 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     # commutes with the resize and joins the map inside the BatchNorm kernels: the conv runs on 4E columns, not 5E.
     Wc = _conv_w(P['cat.conv.weight'], T)
     fold = _cat_fold_operands(P, S['br'])
-    Wcf, cconst = ops.lawin_cat_fold(P['cat.conv.weight'].detach().view(E, 5 * E), *fold, E, T)
+    Wcf, Wct_sum, cconst = ops.lawin_cat_fold(P['cat.conv.weight'].detach().view(E, 5 * E), *fold, E, T)
     vb = ops.gemm_nt(ap, Wc[:, 4 * E:], bias=cconst, out_f32=True)
     z8 = ops.gemm_nt(cat5, Wcf)
     if training:
@@ -174,7 +174,7 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     else:
         fused = ops.bn_apply(zl, stl, P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'], act=1, mask=drop_mask, rows_per_image=rpi4)
         seg = ops.gemm_nt(fused, _conv_w(P['linear_pred.weight'], T), bias=P['linear_pred.bias'])
-    S.update(z8=z8, vb=vb, stc=stc, cat2=cat2, zl=zl, stl=stl, fused=fused, drop_mask=drop_mask, training=training)
+    S.update(z8=z8, vb=vb, Wct_sum=Wct_sum, stc=stc, cat2=cat2, zl=zl, stl=stl, fused=fused, drop_mask=drop_mask, training=training)
     return seg, S
 
 
@@ -215,7 +215,9 @@ def head_backward(P, S, dseg, E):
     G['cat.conv.weight'] = Gc
     ops.gemm_tn(dz8, S['cat5'], out=Gc[:, :4 * E])
     Wct = w_bwd(P['cat.conv.weight'], T)                        # [5E, E]
-    dcat5 = ops.gemm_nt(dz8, Wct[:4 * E])                       # gradients of the concat's slices [feat, feat + BN(z_r)], as the reference has them
+    # columns E..4E: gradients of the concat's slices feat + BN(z_r); columns 0..E: the SUM of all four slice gradients, i.e. the fan-in
+    # on feat (short path + three residuals) straight from the GEMM over the summed weight block
+    dcat5 = ops.gemm_nt(dz8, S['Wct_sum'])
     feat = S['cat5'][:, :E]
     # image-pool branch: the gradient of the per-image vector is the per-image column sum of dz8 (the resize preserves sums)
     dvb32 = ops.colsum(dz8, groups=B)
@@ -230,7 +232,7 @@ def head_backward(P, S, dseg, E):
     # GEMM epilogue as a row scale
     pool_vec = ops.gemm_nt(dzp, w_bwd(P['image_pool.1.conv.weight'], T), out_f32=True, rowscale=_const(dzp.device, 1.0 / (H8 * W8)),
                            rows_per_scale=dzp.shape[0])
-    acc = ops.sum_slices(dcat5, 4, E, E, bvec=pool_vec, rows_per_image=H8 * W8)
+    acc = dcat5[:, :E]                                          # pool_vec (the broadcast of the pooled branch) joins in lawin_pool_bwd
     dGs, amaxs = [], []
     for k, (r, heads) in enumerate(LAWIN_BRANCHES):
         p, br = f'lawin_{r}', S['br'][k]
@@ -238,7 +240,7 @@ def head_backward(P, S, dseg, E):
         G.update({f'{p}.{n}': g for n, g in Gb.items()})
         dGs.append(dG)
         amaxs.append(br['amax'])
-    dfeat = ops.lawin_pool_bwd(dGs, amaxs, B, H8, W8, E, T, base=acc)
+    dfeat = ops.lawin_pool_bwd(dGs, amaxs, B, H8, W8, E, T, base=acc, bvec=pool_vec)
     # linear_fuse and the per-level embeddings
     dzf, dgb = ops.bn_bwd(dfeat, S['zf'], S['stf'], P['linear_fuse.bn.weight'], P['linear_fuse.bn.bias'], act=1, training=training)
     bn_grads('linear_fuse.bn', dgb)

@@ -550,7 +550,7 @@ def bn_bwd_up_to_input(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, trai
 # ------------------------------------------------------------------ LawinHead: branch BatchNorms folded into the `cat` conv
 def lawin_cat_fold(W, stats, gammas, betas, E, dtype):
     """W: cat conv weight [E, >= 4E] fp32 (row stride = W.stride(0)); stats / gammas / betas: three each (branches r = 8, 4, 2).
-    -> (folded weight [E, 4E] in dtype, constant [E] fp32)."""
+    -> (folded weight [E, 4E] in dtype, Wt [4E, E] = [(W_0+W_1+W_2+W_3)^T; W_1^T; W_2^T; W_3^T] in dtype, constant [E] fp32)."""
     dev = _dev(W)
     rows, cols, ldw = _mat(W, 'W')
     if W.dtype != torch.float32 or rows != E or cols < 4 * E:
@@ -558,10 +558,11 @@ def lawin_cat_fold(W, stats, gammas, betas, E, dtype):
     for t in list(stats) + list(gammas) + list(betas):
         _f32(t, 'stats/gamma/beta')
     Wo = torch.empty((E, 4 * E), dtype=dtype, device=dev)
+    Wt = torch.empty((4 * E, E), dtype=dtype, device=dev)
     cc = torch.empty(E, dtype=torch.float32, device=dev)
     check(lib().ss_lawin_cat_fold(_DT[dtype], _p(W), ldw, *[_p(t) for t in stats], *[_p(t) for t in gammas], *[_p(t) for t in betas], E,
-                                  _p(Wo), _p(cc), _stream()))
-    return Wo, cc
+                                  _p(Wo), _p(Wt), _p(cc), _stream()))
+    return Wo, Wt, cc
 
 
 def lawin_cat_wgrad_fix(G, stats, gammas, betas, dvb, B, E):
@@ -728,7 +729,7 @@ def lawin_pool_fwd(feat, B, H, W, r):
     return G, amax
 
 
-def lawin_pool_bwd(dGs, amaxs, B, H, W, C, dtype, base=None):
+def lawin_pool_bwd(dGs, amaxs, B, H, W, C, dtype, base=None, bvec=None):
     """dGs/amaxs: lists for r = 8, 4, 2 -> d(feat) [B*H*W, C] (= base + pooled-context gradient)."""
     dev = _dev(dGs[0])
     for r, d, a in zip((8, 4, 2), dGs, amaxs):
@@ -741,9 +742,10 @@ def lawin_pool_bwd(dGs, amaxs, B, H, W, C, dtype, base=None):
         rb, Cb, ldb = _mat(base, 'base')
         if (rb, Cb) != (B * H * W, C) or base.dtype != dtype:
             raise ValueError('lawin_pool_bwd: bad base')
+    _f32(bvec, 'bvec', B * C)
     out = torch.empty((B * H * W, C), dtype=dtype, device=dev)
     check(lib().ss_lawin_pool_bwd(_DT[dtype], _p(dGs[0]), _p(dGs[1]), _p(dGs[2]), _p(amaxs[0]), _p(amaxs[1]), _p(amaxs[2]),
-                                  _p(base), ldb, _p(out), C, B, H, W, C, _stream()))
+                                  _p(base), ldb, _p(bvec), _p(out), C, B, H, W, C, _stream()))
     return out
 
 
