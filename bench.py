@@ -114,6 +114,8 @@ def entry_work(name, a):
     if name == 'ss_bn_bwd_up2_dx':
         B, hi, wi = a[6:9]
         return 'hbm', 1.0 * B * (3 * hi * wi + 2 * 4 * hi * wi) * a[16] * _sz(a[0])
+    if name == 'ss_bn_bwd_coef':
+        return 'hbm', 3.0 * a[11] * a[12] * _sz(a[0])
     if name == 'ss_bn_apply_classify':
         return 'hbm', 1.0 * a[13] * (a[14] + a[10]) * _sz(a[0])
     if name == 'ss_bn_bwd_classify':

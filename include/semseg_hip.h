@@ -100,6 +100,10 @@ int ss_gemm_nt_bn_stats(int dtype, const void* A, int64_t lda, const void* B, in
                         int64_t K, const void* res, int64_t ldr, float eps, float momentum, float* stats, float* running_mean,
                         float* running_var, int64_t* num_batches_tracked, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
+/* second pass of ss_bn_bwd alone (act 0, no mask) with the first-pass means given: coef = [2, C] (mean dy, mean dy * xhat) */
+int ss_bn_bwd_coef(int dtype, const void* dy, int64_t ldd, const void* z, int64_t ldz, const float* stats, const float* gamma,
+                   const float* beta, const float* coef, void* dz, int64_t ldo, int64_t rows, int C, hipStream_t stream);
+
 /* The same three steps for a BatchNorm whose input is a bilinear resize (tnf.interpolate(..., mode='bilinear', align_corners=False),
  * modules/lawin.py:213-222, followed by ConvModule `cat`'s BatchNorm2d + Mish, lawin.py:101-105) of the coarse map x [B*hi*wi, C]:
  * the kernels read z = resize(x) through its four taps (the bits ss_bilinear_fwd would store), so the resized [B*ho*wo, C]
@@ -265,6 +269,12 @@ int ss_lawin_cat_fold(int dtype, const float* W, int64_t ldw, const float* stats
                       const float* gamma8, const float* gamma4, const float* gamma2, const float* beta8, const float* beta4,
                       const float* beta2, int E, void* Wout, void* Wt /* [4E, E]: (W_0+W_1+W_2+W_3)^T, W_1^T, W_2^T, W_3^T */, float* cconst,
                       hipStream_t stream);
+/* First pass of the three branch BatchNorm backwards from G = dz^T [feat | z_8 | z_4 | z_2] (BEFORE ss_lawin_cat_wgrad_fix), the cat conv
+ * weight W and dvb: the gradient at BN_r's output is dz . W_r, so its column sums are sum_n W_r[n][k] colsum(dz)[n] and
+ * sum_n W_r[n][k] G_r[n][k].  dgb = [3][2][E] (dgamma, dbeta per branch), coef = [3][2][E] for ss_bn_bwd_coef; rows = B*H*W. */
+int ss_lawin_branch_bn_sums(const float* G, int64_t ldg, const float* W, int64_t ldw, const float* stats8, const float* stats4,
+                            const float* stats2, const float* dvb, int B, int E, int64_t rows, int training, float* dgb, float* coef,
+                            hipStream_t stream);
 int ss_lawin_cat_wgrad_fix(float* G, int64_t ldg, const float* stats8, const float* stats4, const float* stats2,
                            const float* gamma8, const float* gamma4, const float* gamma2, const float* beta8, const float* beta4,
                            const float* beta2, const float* dvb, int B, int E, hipStream_t stream);

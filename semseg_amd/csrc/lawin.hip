@@ -671,3 +671,48 @@ extern "C" int ss_lawin_cat_wgrad_fix(float* G, int64_t ldg, const float* stats8
     SS_LAUNCH_CHECK();
     return 0;
 }
+
+// First pass of the three branch BatchNorm backwards without touching the S/8 maps.  The gradient reaching BN_r's output is
+// g_r = dz . W_r (dz: gradient of the cat conv's output), so its column sums are bilinear forms of quantities the step already has:
+//     sum_m g_r[m][k]            = sum_n W_r[n][k] * colsum(dz)[n]
+//     sum_m g_r[m][k] z_r[m][k]  = sum_n W_r[n][k] * G'_r[n][k],        G' = dz^T [feat | z_8 | z_4 | z_2]  (the folded weight gradient)
+// -> dgb_r = (dgamma, dbeta) and coef_r = (mean g, mean g * xhat) for the second pass (ss_bn_bwd_coef).  Call BEFORE
+// ss_lawin_cat_wgrad_fix rewrites G'.  A workgroup takes 16 channels of one branch, 16 row parts each (fixed-order combine).
+__global__ __launch_bounds__(256) void lawin_branch_bn_sums_kernel(const float* __restrict__ G, int64_t ldg, const float* __restrict__ W, int64_t ldw,
+                                                                   CatFoldArgs a, const float* __restrict__ dvb, int B, int E, double inv_rows, int training,
+                                                                   float* __restrict__ dgb, float* __restrict__ coef) {
+    extern __shared__ float cs[];                             // colsum(dz) [E], then 2 x 16 x 16 doubles of partial sums
+    __shared__ double red[2][16][17];
+    for (int n = threadIdx.x; n < E; n += 256) { float t = 0.f; for (int b = 0; b < B; ++b) t += dvb[(int64_t)b * E + n]; cs[n] = t; }
+    __syncthreads();
+    const int r = blockIdx.y, kl = threadIdx.x & 15, part = threadIdx.x >> 4, k = blockIdx.x * 16 + kl;
+    double sg = 0.0, sgz = 0.0;
+    if (k < E) {
+        const float* w = W + (int64_t)(r + 1) * E + k;
+        const float* g = G + (int64_t)(r + 1) * E + k;
+#pragma unroll 4
+        for (int n = part; n < E; n += 16) { const float wv = w[(int64_t)n * ldw]; sg += (double)wv * cs[n]; sgz += (double)wv * g[(int64_t)n * ldg]; }
+    }
+    red[0][part][kl] = sg; red[1][part][kl] = sgz;
+    __syncthreads();
+    if (part != 0 || k >= E) return;
+    sg = 0.0; sgz = 0.0;
+    for (int q = 0; q < 16; ++q) { sg += red[0][q][kl]; sgz += red[1][q][kl]; }
+    const double mu = a.stats[r][k], rs = a.stats[r][E + k];
+    const double sgx = rs * (sgz - mu * sg);
+    dgb[((int64_t)r * 2 + 0) * E + k] = (float)sgx;
+    dgb[((int64_t)r * 2 + 1) * E + k] = (float)sg;
+    coef[((int64_t)r * 2 + 0) * E + k] = training ? (float)(sg * inv_rows) : 0.f;
+    coef[((int64_t)r * 2 + 1) * E + k] = training ? (float)(sgx * inv_rows) : 0.f;
+}
+extern "C" int ss_lawin_branch_bn_sums(const float* G, int64_t ldg, const float* W, int64_t ldw, const float* stats8, const float* stats4,
+                                       const float* stats2, const float* dvb, int B, int E, int64_t rows, int training, float* dgb, float* coef,
+                                       hipStream_t stream) {
+    SS_CHECK(G && W && stats8 && stats4 && stats2 && dvb && dgb && coef && B > 0 && E > 0 && rows > 0 && ldg >= 4 * (int64_t)E && ldw >= 4 * (int64_t)E &&
+             E <= 8192, "ss_lawin_branch_bn_sums: bad arguments");
+    CatFoldArgs a{{stats8, stats4, stats2}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    hipLaunchKernelGGL(lawin_branch_bn_sums_kernel, dim3((unsigned)cdiv(E, 16), 3), dim3(256), E * sizeof(float), stream, G, ldg, W, ldw, a, dvb, B, E,
+                       1.0 / (double)rows, training, dgb, coef);
+    SS_LAUNCH_CHECK();
+    return 0;
+}

@@ -686,6 +686,21 @@ extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, 
     return 0;
 }
 
+// Second pass alone, for a BatchNorm without activation whose first-pass sums came from elsewhere (ss_lawin_branch_bn_sums):
+// dz = gamma * rstd * (dy - coef[0] - xhat * coef[1]),  coef = [2, C] (mean dy, mean dy * xhat; zeros in eval mode)
+extern "C" int ss_bn_bwd_coef(int dtype, const void* dy, int64_t ldd, const void* z, int64_t ldz, const float* stats, const float* gamma,
+                              const float* beta, const float* coef, void* dz, int64_t ldo, int64_t rows, int C, hipStream_t stream) {
+    SS_CHECK(dy && z && stats && gamma && beta && coef && dz && rows > 0 && C > 0 && C % 8 == 0, "ss_bn_bwd_coef: bad arguments");
+    SS_CHECK(ldd >= C && ldz >= C && ldo >= C && ldd % 8 == 0 && ldz % 8 == 0 && ldo % 8 == 0, "ss_bn_bwd_coef: bad leading dimensions");
+    ColGeom g = col_geom(rows, C);
+    BnWalk w{g.cpb, g.rpb};
+    const int blocks2 = bn_walk_blocks(rows, g.rpb);
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, 0, false, true>), dim3(blocks2), dim3(256), 0, stream, (const T*)dy, ldd, (const T*)z, ldz, stats,
+                                          gamma, beta, (const float*)nullptr, (int64_t)0, -1, coef, (T*)dz, ldo, (float*)nullptr, rows, C, w, UpGeom{}));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
 // the same with z = resize(x) read through its taps (no mask): dz is the gradient of the RESIZED map, [B*ho*wo, C]
 extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi, int ho, int wo,
                             const float* stats, const float* gamma, const float* beta, int training, void* dz, int64_t ldo,

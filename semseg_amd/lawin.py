@@ -71,12 +71,17 @@ def branch_forward(P, Bf, qtok, G, B, H, W, r, heads, E, training, out=None, fol
     return o, dict(G=G, Wm=Wm, ctx=ctx, pg=pg, th=th, y=y, lse=lse, z=z, st=st)
 
 
-def branch_backward(P, br, dout, qtok, acc, B, H, W, r, heads, E, training):
+def branch_backward(P, br, dout, qtok, acc, B, H, W, r, heads, E, training, bn_sums=None):
     """dout: gradient of the branch output [B*H*W, E].  acc: running gradient of the query map (None, or the contributions so far;
     the residual share `dout` itself is NOT added here).  -> (acc + theta path, dG fp32 [grid rows, E], {param: grad})."""
     T = dout.dtype
     inter, G = max(E // 2, 1), {}
-    dz, dgb = ops.bn_bwd(dout, br['z'], br['st'], P['conv_out.1.weight'], P['conv_out.1.bias'], act=0, training=training)
+    if bn_sums is None:
+        dz, dgb = ops.bn_bwd(dout, br['z'], br['st'], P['conv_out.1.weight'], P['conv_out.1.bias'], act=0, training=training)
+    else:
+        # LawinHead: the first-pass sums came out of the cat conv's weight gradient (ops.lawin_branch_bn_sums): second pass only
+        dgb, coef = bn_sums
+        dz = ops.bn_bwd_coef(dout, br['z'], br['st'], P['conv_out.1.weight'], P['conv_out.1.bias'], coef)
     G['conv_out.1.weight'], G['conv_out.1.bias'] = dgb[0], dgb[1]
     G['conv_out.0.weight'] = ops.gemm_tn(dz, br['y'])
     dy = ops.gemm_nt(dz, w_bwd(P['conv_out.0.weight'], T))
@@ -221,7 +226,9 @@ def head_backward(P, S, dseg, E):
     feat = S['cat5'][:, :E]
     # image-pool branch: the gradient of the per-image vector is the per-image column sum of dz8 (the resize preserves sums)
     dvb32 = ops.colsum(dz8, groups=B)
-    ops.lawin_cat_wgrad_fix(Gc, *_cat_fold_operands(P, S['br']), dvb32, B, E)
+    fold = _cat_fold_operands(P, S['br'])
+    br_dgb, br_coef = ops.lawin_branch_bn_sums(Gc, P['cat.conv.weight'].detach().view(E, 5 * E), fold[0], dvb32, B, E, B * H8 * W8, training)
+    ops.lawin_cat_wgrad_fix(Gc, *fold, dvb32, B, E)
     dvb = ops.cast(dvb32, T)
     ops.gemm_tn(dvb, S['ap'], out=Gc[:, 4 * E:])
     dap = ops.gemm_nt(dvb, Wct[4 * E:])
@@ -236,7 +243,8 @@ def head_backward(P, S, dseg, E):
     dGs, amaxs = [], []
     for k, (r, heads) in enumerate(LAWIN_BRANCHES):
         p, br = f'lawin_{r}', S['br'][k]
-        acc, dG, Gb = branch_backward(_sub(P, p + '.'), br, dcat5[:, (k + 1) * E:(k + 2) * E], feat, acc, B, H8, W8, r, heads, E, training)
+        acc, dG, Gb = branch_backward(_sub(P, p + '.'), br, dcat5[:, (k + 1) * E:(k + 2) * E], feat, acc, B, H8, W8, r, heads, E, training,
+                                      bn_sums=(br_dgb[k], br_coef[k]))
         G.update({f'{p}.{n}': g for n, g in Gb.items()})
         dGs.append(dG)
         amaxs.append(br['amax'])

@@ -565,6 +565,34 @@ def lawin_cat_fold(W, stats, gammas, betas, E, dtype):
     return Wo, Wt, cc
 
 
+def lawin_branch_bn_sums(G, W, stats, dvb, B, E, rows, training):
+    """-> dgb [3, 2, E] (dgamma, dbeta of the three branch BatchNorms), coef [3, 2, E] for bn_bwd_coef; G before lawin_cat_wgrad_fix."""
+    dev = _dev(G)
+    _, _, ldg = _mat(G, 'G')
+    _, _, ldw = _mat(W, 'W')
+    if G.dtype != torch.float32 or W.dtype != torch.float32:
+        raise ValueError('lawin_branch_bn_sums: G and W must be fp32')
+    _f32(dvb, 'dvb', B * E)
+    dgb = torch.empty((3, 2, E), dtype=torch.float32, device=dev)
+    coef = torch.empty((3, 2, E), dtype=torch.float32, device=dev)
+    check(lib().ss_lawin_branch_bn_sums(_p(G), ldg, _p(W), ldw, *[_p(t) for t in stats], _p(dvb), B, E, rows, int(training), _p(dgb), _p(coef),
+                                        _stream()))
+    return dgb, coef
+
+
+def bn_bwd_coef(dy, z, stats, gamma, beta, coef):
+    """second pass of bn_bwd (act 0, no mask) with given first-pass means coef [2, C] -> dz."""
+    dev = _dev(z)
+    rows, C, ldz = _mat(z, 'z')
+    rd, Cd, ldd = _mat(dy, 'dy')
+    if (rd, Cd) != (rows, C) or dy.dtype != z.dtype:
+        raise ValueError('bn_bwd_coef: dy/z mismatch')
+    _f32(stats, 'stats', 2 * C), _f32(gamma, 'gamma', C), _f32(beta, 'beta', C), _f32(coef, 'coef', 2 * C)
+    dz = torch.empty((rows, C), dtype=z.dtype, device=dev)
+    check(lib().ss_bn_bwd_coef(dt(z), _p(dy), ldd, _p(z), ldz, _p(stats), _p(gamma), _p(beta), _p(coef), _p(dz), C, rows, C, _stream()))
+    return dz
+
+
 def lawin_cat_wgrad_fix(G, stats, gammas, betas, dvb, B, E):
     """in place on the first 4E columns of G [E, ld]: gradient of the folded GEMM's weight -> gradient of the cat conv weight."""
     _dev(G)
