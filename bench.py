@@ -78,7 +78,7 @@ def entry_work(name, a):
         return 'mfma', 2.0 * a[8] * a[9] * a[10]
     if name == 'ss_gemm_nt_bn_stats':
         return 'mfma', 2.0 * a[7] * a[8] * a[9]
-    if name in ('ss_gemm_tn', 'ss_gemm_tn_colsum'):
+    if name in ('ss_gemm_tn', 'ss_gemm_tn_colsum', 'ss_gemm_tn_colsum_keep'):
         return 'mfma', 2.0 * a[7] * a[8] * a[9]
     if name == 'ss_mit_attn_fwd':
         B, N, Nk, h, D = a[5:10]
@@ -171,7 +171,7 @@ def entry_bytes(name, a):
     if name == 'ss_gemm_nt_bn_stats':
         M, N, K = a[7:10]
         return (M * K + N * K + M * N * (2 if a[10] else 1)) * _sz(a[0])
-    if name in ('ss_gemm_tn', 'ss_gemm_tn_colsum'):
+    if name in ('ss_gemm_tn', 'ss_gemm_tn_colsum', 'ss_gemm_tn_colsum_keep'):
         M, N, K = a[7:10]
         return (K * M + K * N) * _sz(a[0]) + M * N * 4
     if name.startswith('ss_conv_patch_'):
@@ -221,7 +221,7 @@ def shape_table(trace):
             M, N, K = a[7:10]
             key = ('ss_gemm_nt', M, N, K, 'res' if a[10] else '', 'stats')
             byt = (M * K + N * K + M * N * (2 if a[10] else 1)) * _sz(a[0])
-        elif name in ('ss_gemm_tn', 'ss_gemm_tn_colsum'):
+        elif name in ('ss_gemm_tn', 'ss_gemm_tn_colsum', 'ss_gemm_tn_colsum_keep'):
             M, N, K = a[7:10]
             key = ('ss_gemm_tn', M, N, K, 'cs' if name.endswith('colsum') else '', '')
             byt = (K * M + K * N) * _sz(a[0]) + M * N * 4

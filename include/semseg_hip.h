@@ -55,6 +55,17 @@ int ss_gemm_tn_colsum(int dtype, const void* A, int64_t lda, const void* B, int6
                       int64_t M, int64_t N, int64_t R, void* workspace, int64_t ws_bytes, int accumulate, float* colsum,
                       int colsum_accumulate, hipStream_t stream);
 
+/* Weight + bias gradient of a Linear inside a DropPath branch (x + drop_path(f(x)), modules/segformer.py:96-97, modules/helpers.py:9-24)
+ * from the UNSCALED output gradient: rows r of A carry the multiplier rowkeep[r / rows_per_keep], which is 0 (sample dropped) or one common
+ * positive value 1/(1-p).  The bf16 tile kernels skip the k-tiles of dropped samples and scale their fp32 slabs, so the scaled copy of the
+ * gradient (one pass over it per branch) is never made.  ss_gemm_tn_keep_ok: 1 when they take the call (bf16, rows_per_keep a multiple
+ * of 64 dividing R, tile-kernel layout); otherwise scale the gradient (ss_rowscale) and call ss_gemm_tn_colsum. */
+int ss_gemm_tn_keep_ok(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t R,
+                       int64_t rows_per_keep);
+int ss_gemm_tn_colsum_keep(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                           int64_t M, int64_t N, int64_t R, void* workspace, int64_t ws_bytes, int accumulate, float* colsum,
+                           int colsum_accumulate, const float* rowkeep, int64_t rows_per_keep, hipStream_t stream);
+
 /* ---- nn.LayerNorm over C on token layout (modules/segformer.py:19,30,77,83,90,93,145-198). mean/rstd: [rows] fp32. */
 int ss_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                      float* rstd, int64_t rows, int C, float eps, hipStream_t stream);

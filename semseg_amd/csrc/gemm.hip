@@ -405,7 +405,27 @@ extern "C" int64_t ss_gemm_tn_workspace(int dtype, int64_t M, int64_t N, int64_t
 
 static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
                         int64_t R, void* workspace, int64_t ws_bytes, int accumulate, float* colsum, int colsum_accumulate,
-                        hipStream_t stream, const PatchMap* pm = nullptr);
+                        hipStream_t stream, const PatchMap* pm = nullptr, const float* rowkeep = nullptr, int64_t rows_per_keep = 0);
+
+// The weight gradient of a layer inside a DropPath branch (modules/segformer.py:96-97 with modules/helpers.py:9-24): rows of sample
+// b carry the multiplier rowkeep[b], which is 0 (dropped) or ONE common positive value.  The bf16 tile kernels skip the k-tiles of
+// dropped samples and scale their slabs, so no scaled copy of the gradient is made; ss_gemm_tn_keep_ok says whether they take the call.
+extern "C" int ss_gemm_tn_keep_ok(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t R,
+                                  int64_t rows_per_keep) {
+    if (dtype != SS_BF16 || rows_per_keep <= 0 || rows_per_keep % 64 || R % rows_per_keep || M % 8 || lda % 8) return 0;
+    if (ss_skinny_tn_ok(B, ldb, M, N) || !ss_fast_tn_ok(A, lda, B, ldb, M, N)) return 0;
+    int ns; int64_t rps;
+    tn_plan(M, N, R, 64, &ns, &rps);
+    return ns <= kColsumWsRows && N % 4 == 0;
+}
+extern "C" int ss_gemm_tn_colsum_keep(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                                      int64_t M, int64_t N, int64_t R, void* workspace, int64_t ws_bytes, int accumulate, float* colsum,
+                                      int colsum_accumulate, const float* rowkeep, int64_t rows_per_keep, hipStream_t stream) {
+    SS_CHECK(colsum && rowkeep && ldc % 4 == 0 && aligned16(C) && ss_gemm_tn_keep_ok(dtype, A, lda, B, ldb, M, N, R, rows_per_keep),
+             "ss_gemm_tn_colsum_keep: shape / layout outside the bf16 tile kernels (ask ss_gemm_tn_keep_ok first)");
+    return gemm_tn_impl(dtype, A, lda, B, ldb, C, ldc, M, N, R, workspace, ws_bytes, accumulate, colsum, colsum_accumulate, stream, nullptr,
+                        rowkeep, rows_per_keep);
+}
 
 extern "C" int ss_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                           int64_t M, int64_t N, int64_t R, void* workspace, int64_t ws_bytes, int accumulate, hipStream_t stream) {
@@ -421,7 +441,7 @@ extern "C" int ss_gemm_tn_colsum(int dtype, const void* A, int64_t lda, const vo
 
 static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
                         int64_t R, void* workspace, int64_t ws_bytes, int accumulate, float* colsum, int colsum_accumulate,
-                        hipStream_t stream, const PatchMap* pm) {
+                        hipStream_t stream, const PatchMap* pm, const float* rowkeep, int64_t rows_per_keep) {
     SS_CHECK(A && B && C && workspace, "ss_gemm_tn: null operand");
     SS_CHECK(M > 0 && N > 0 && R > 0 && N < (1 << 30) && M < (1 << 30), "ss_gemm_tn: bad shape");
     SS_CHECK(lda >= M && (pm || ldb >= N) && ldc >= N, "ss_gemm_tn: leading dimension smaller than the row");
@@ -456,7 +476,7 @@ static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, in
     } else if (dtype == SS_BF16 && ss_fast_tn_ok(A, lda, B, ldb, M, N)) {
         FastGemm f{};
         f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = workspace; f.M = M; f.N = (int)N; f.K = R; f.lda = lda; f.ldb = ldb; f.ldc = N;
-        f.k_per_split = rps;
+        f.k_per_split = rps; f.rowscale = rowkeep; f.rows_per_scale = rows_per_keep > 0 ? rows_per_keep : 1;
         if (colsum && ns <= kColsumWsRows) { f.colsum_ws = cs_ws; cs_fused = true; }
         int rc = big && ss_big_tn_ok(f, ns) ? ss_big_tn_launch(f, ns, stream) : ss_fast_tn_launch(f, ns, stream);
         if (rc) return rc;

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(FastGemm p) {
     };
 
     const bool do_cs = p.colsum_ws && n0 == 0;
-    float cs = 0.f;
+    float cs = 0.f, keep_mul = p.rowscale ? 0.f : 1.f;
     if (kbeg < kend) {
         gload(kbeg);
         lstore();
@@ -225,8 +225,12 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(FastGemm p) {
         for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
             const bool more = k0 + BK < kend;
             if (more) gload(k0 + BK);
+            // row keep (DropPath in the backward): a k-tile lies inside one sample; tiles of dropped samples contribute nothing and the
+            // kept ones share ONE multiplier, applied to the slab at the end
+            const float kv = p.rowscale ? p.rowscale[k0 / p.rows_per_scale] : 1.f;
+            if (kv != 0.f) keep_mul = kv;
 #pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
+            for (int ks = 0; ks < (kv != 0.f ? BK / 16 : 0); ++ks) {
                 bf16x8 fa[2], fb[TN];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) fa[a] = trfrag(As, PA, ks, wm * 64 + a * 32);
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(FastGemm p) {
         }
     }
     if (do_cs) {                                          // lane = column (lane & 31) of the A fragment, k split over lane halves
-        const float t = cs + __shfl_xor(cs, 32);
+        const float t = (cs + __shfl_xor(cs, 32)) * keep_mul;
         const int m = m0 + wm * 64 + wn * 32 + li;
         if (lh == 0 && m < p.M) p.colsum_ws[(int64_t)split * p.M + m] = t;
     }
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(FastGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < p.M) C[(int64_t)row * p.N + col] = acc[a][b][r];
+                if (row < p.M) C[(int64_t)row * p.N + col] = acc[a][b][r] * keep_mul;
             }
         }
 }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(FastGemm p) {
     };
 
     const bool do_cs = p.colsum_ws && n0 == 0;
-    float cs = 0.f;
+    float cs = 0.f, keep_mul = p.rowscale ? 0.f : 1.f;
     if (nk > 0) issue(0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -94,8 +94,11 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(FastGemm p) {
         if (kt + 1 < nk) issue(kt + 1);
         const char* As = smem + (kt & 1) * STAGE;
         const char* Bs = As + IMG;
+        // row keep (see gemm_tn_bf16_kernel): k-tiles of dropped samples are skipped, the kept ones share one multiplier
+        const float kv = p.rowscale ? p.rowscale[(kbeg + (int64_t)kt * BK) / p.rows_per_scale] : 1.f;
+        if (kv != 0.f) keep_mul = kv;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < (kv != 0.f ? BK / 16 : 0); ++ks) {
             bf16x8 fa[2], fb[4];
 #pragma unroll
             for (int a = 0; a < 2; ++a) fa[a] = trfrag(As, ks, wm * 64 + a * 32);
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(FastGemm p) {
         }
     }
     if (do_cs) {                                       // lane = column (lane & 31) of the A fragment, k split over the lane halves
-        const float t = cs + __shfl_xor(cs, 32);
+        const float t = (cs + __shfl_xor(cs, 32)) * keep_mul;
         const int m = m0 + wm * 64 + wn * 32 + li;
         if (lh == 0 && m < p.M) p.colsum_ws[(int64_t)split * p.M + m] = t;
     }
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(FastGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < p.M) C[(int64_t)row * p.N + col] = acc[a][b][r];
+                if (row < p.M) C[(int64_t)row * p.N + col] = acc[a][b][r] * keep_mul;
             }
         }
 }

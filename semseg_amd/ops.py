@@ -131,6 +131,32 @@ def gemm_tn(a, b, out=None, accumulate=False, colsum=False):
     return out, cs
 
 
+def gemm_tn_keep_ok(a, b, rows_per_keep):
+    """whether gemm_tn_keep takes a [R, M], b [R, N] with one keep multiplier per rows_per_keep rows (else: rowscale + gemm_tn)"""
+    if not a.is_cuda or a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+        return False
+    R, M, lda = _mat(a, 'a')
+    Rb, N, ldb = _mat(b, 'b')
+    return R == Rb and bool(lib().ss_gemm_tn_keep_ok(dt(a), _p(a), lda, _p(b), ldb, M, N, R, rows_per_keep))
+
+
+def gemm_tn_keep(a, b, rowkeep, rows_per_keep):
+    """(dW [M, N], db [M]) = ((k * a)^T @ b, column sums of k * a) with k[r] = rowkeep[r // rows_per_keep] in {0, c}: the DropPath-scaled
+    weight / bias gradient from the unscaled gradient a (k-tiles of dropped samples are skipped, the slabs carry c)."""
+    dev = _dev(a)
+    R, M, lda = _mat(a, 'a')
+    Rb, N, ldb = _mat(b, 'b')
+    _f32(rowkeep, 'rowkeep')
+    if R != Rb or rowkeep.numel() * rows_per_keep != R:
+        raise ValueError('gemm_tn_keep: shapes do not match')
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    cs = torch.empty(M, dtype=torch.float32, device=dev)
+    ws = workspace(dev, lib().ss_gemm_tn_workspace(dt(a), M, N, R))
+    check(lib().ss_gemm_tn_colsum_keep(dt(a), _p(a), lda, _p(b), ldb, _p(out), N, M, N, R, _p(ws), ws.numel(), 0, _p(cs), 0, _p(rowkeep),
+                                       rows_per_keep, _stream()))
+    return out, cs
+
+
 # ------------------------------------------------------------------ norms / reductions
 def layernorm_fwd(x, gamma, beta, eps=1e-5):
     dev = _dev(x)

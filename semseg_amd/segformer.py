@@ -39,6 +39,21 @@ def linear_grads(dout, x_in, want_bias=True):
     return ops.gemm_tn(dout, x_in), None
 
 
+def branch_head_grads(dout, x_in, w_t, keep, rows):
+    """Backward of the LAST Linear of a residual branch under DropPath (modules/segformer.py:96-97): dout is the gradient of the block
+    output, the branch sees keep[b] * dout.  -> (dW, db, d(x_in)).  Where the tile kernels take the shape the scaled gradient is never
+    materialised: the weight-gradient GEMM skips dropped samples and scales its slabs, the data-gradient GEMM scales rows in its epilogue."""
+    if keep is None:
+        dW, db = linear_grads(dout, x_in)
+        return dW, db, ops.gemm_nt(dout, w_t)
+    if ops.gemm_tn_keep_ok(dout, x_in, rows):
+        dW, db = ops.gemm_tn_keep(dout, x_in, keep, rows)
+        return dW, db, ops.gemm_nt(dout, w_t, rowscale=keep, rows_per_scale=rows)
+    g = ops.rowscale(dout, keep, rows)
+    dW, db = linear_grads(g, x_in)
+    return dW, db, ops.gemm_nt(g, w_t)
+
+
 # ------------------------------------------------------------------ attention (modules/segformer.py:21-41)
 def attn_forward(P, x, B, h, w, head, sr, res=None, keep=None):
     """x: normed tokens [B*N, C].  P: dict of fp32 parameters.  -> out [B*N, C], saved-state dict."""
@@ -70,13 +85,12 @@ def attn_forward(P, x, B, h, w, head, sr, res=None, keep=None):
     return out, S
 
 
-def attn_backward(P, S, dout, B, h, w, head, sr):
-    """dout: gradient of the projection output (already DropPath-scaled).  -> dx, {param: grad}."""
+def attn_backward(P, S, dout, B, h, w, head, sr, keep=None):
+    """dout: gradient of the block output on this branch; keep: the branch's DropPath multipliers [B] (or None).  -> dx, {param: grad}."""
     T = dout.dtype
     N, C = h * w, dout.shape[1]
     G = {}
-    G['proj.weight'], G['proj.bias'] = linear_grads(dout, S['ao'])
-    dao = ops.gemm_nt(dout, w_bwd(P['proj.weight'], T))
+    G['proj.weight'], G['proj.bias'], dao = branch_head_grads(dout, S['ao'], w_bwd(P['proj.weight'], T), keep, N)
     dq, dkv = ops.mit_attn_bwd(S['q'], S['kv'], S['ao'], dao, S['lse'], B, N, S['Nk'], head)
     G['kv.weight'], G['kv.bias'] = linear_grads(dkv, S['xr'])
     dxr = ops.gemm_nt(dkv, w_bwd(P['kv.weight'], T))
@@ -113,11 +127,10 @@ def mlp_forward(P, x, B, h, w, res=None, keep=None):
     return out, {'x': x, 'h1': h1, 'a2': a2, 'w9c': w9c}
 
 
-def mlp_backward(P, S, dout, B, h, w):
+def mlp_backward(P, S, dout, B, h, w, keep=None):
     T = dout.dtype
     G = {}
-    G['fc2.weight'], G['fc2.bias'] = linear_grads(dout, S['a2'])
-    da2 = ops.gemm_nt(dout, w_bwd(P['fc2.weight'], T))
+    G['fc2.weight'], G['fc2.bias'], da2 = branch_head_grads(dout, S['a2'], w_bwd(P['fc2.weight'], T), keep, h * w)
     Ch = da2.shape[1]
     if h * w >= FUSED_DW_MIN_PIXELS:
         # one pass: dh1 and the tap / bias gradients together, g = da2 * GELU'(u) stays on chip (3 tensor passes instead of 5)
@@ -223,11 +236,9 @@ class BlockFn(_ParamFn):
     def bwd(P, S, dx3, meta):
         B, h, w, head, sr, keep_a, keep_m = meta
         N = h * w
-        g = dx3 if keep_m is None else ops.rowscale(dx3, keep_m, N)
-        dn2, Gm = mlp_backward(_sub(P, 'mlp.'), S['Sm'], g, B, h, w)
+        dn2, Gm = mlp_backward(_sub(P, 'mlp.'), S['Sm'], dx3, B, h, w, keep=keep_m)
         dx2, dgb2 = ops.layernorm_bwd(dn2, S['x2'], S['m2'], S['r2'], P['norm2.weight'], res=dx3)
-        g = dx2 if keep_a is None else ops.rowscale(dx2, keep_a, N)
-        dn1, Ga = attn_backward(_sub(P, 'attn.'), S['Sa'], g, B, h, w, head, sr)
+        dn1, Ga = attn_backward(_sub(P, 'attn.'), S['Sa'], dx2, B, h, w, head, sr, keep=keep_a)
         dx, dgb1 = ops.layernorm_bwd(dn1, S['x'], S['m1'], S['r1'], P['norm1.weight'], res=dx2)
         G = {'norm1.weight': dgb1[0], 'norm1.bias': dgb1[1], 'norm2.weight': dgb2[0], 'norm2.bias': dgb2[1]}
         G.update(_pre(Ga, 'attn.'))

@@ -116,6 +116,30 @@ def test_gemm_tn_with_bias_gradient(ops, dtype, R, M, N):
     assert float((cs.cpu() - refcs).abs().max()) <= 1e-4 * float(q(a, dtype).abs().double().sum(0).max())
 
 
+@pytest.mark.parametrize('R,M,N,rpk', [(4096, 64, 256, 1024), (8192, 320, 1280, 1024), (16384, 512, 2048, 1024), (65536, 128, 128, 4096),
+                                       (1024, 64, 64, 64), (12288, 512, 512, 4096)])
+def test_gemm_tn_droppath_keep(ops, R, M, N, rpk):
+    """ss_gemm_tn_colsum_keep: weight / bias gradient under DropPath (modules/helpers.py:9-24) from the unscaled gradient; equals the plain
+    entry point on the row-scaled gradient up to the rounding of that scaled copy, and is exactly zero when every sample is dropped."""
+    dtype = torch.bfloat16
+    a, b = rnd(R, M), rnd(R, N, seed=1)
+    nb = R // rpk
+    keep = (torch.rand(nb, generator=torch.Generator().manual_seed(R)) > 0.35).float() / 0.65
+    keep[0] = 0.0
+    if nb > 1:
+        keep[-1] = 1 / 0.65
+    ad, bd = dev(a, dtype), dev(b, dtype)
+    assert ops.gemm_tn_keep_ok(ad, bd, rpk)
+    dW, db = ops.gemm_tn_keep(ad, bd, dev(keep), rpk)
+    k = keep.repeat_interleave(rpk)[:, None]
+    ref = (q(a, dtype) * k).t() @ q(b, dtype)
+    assert rel(dW, ref) < 2e-3
+    assert rel(db, (q(a, dtype) * k).sum(0)) < 2e-3
+    dW0, db0 = ops.gemm_tn_keep(ad, bd, torch.zeros(nb, device='cuda'), rpk)
+    assert float(dW0.abs().max()) == 0 and float(db0.abs().max()) == 0
+    assert not ops.gemm_tn_keep_ok(ad, bd, 96) and not ops.gemm_tn_keep_ok(ad.float(), bd.float(), rpk)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_gemm_nt_strided(ops, dtype):
     big_a, b = rnd(200, 96), rnd(40, 32, seed=1)
