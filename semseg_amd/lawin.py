@@ -26,6 +26,13 @@ def _conv_w(w, dtype):
     return w_fwd(w, dtype)
 
 
+def _rows_on_lines(rows, cols, dtype, dev):
+    """[rows, cols] view of a buffer whose row pitch is a multiple of 128 bytes: with E + 48 = 560 bf16 columns a 64-column k-tile of a
+    contiguous row straddles two cache lines in 3 rows of 4, and the GEMM tile loaders are bound by the number of lines they request."""
+    per = 128 // torch.empty((), dtype=dtype).element_size()
+    return torch.empty((rows, (cols + per - 1) // per * per), dtype=dtype, device=dev)[:, :cols]
+
+
 def _conv_bn_stats(a, w, P, Bf, prefix, training, res=None, out=None):
     """bias-free 1x1 conv (+ res) followed by a BatchNorm's statistics: in training the column sums ride in the GEMM's copy-out"""
     if training:
@@ -165,10 +172,17 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
                               Bf['cat.bn.num_batches_tracked'], bvec=vb)
     else:
         stc = ops.bn_eval_stats(Bf['cat.bn.running_mean'], Bf['cat.bn.running_var'])
-    cat2 = torch.empty((R4, E + 48), dtype=T, device=dev)
+    # the concat [up(cat) | linear_c1] has E + 48 columns: its rows are padded to whole 64-column k-tiles (128-byte lines) with columns
+    # that are written as exact zeros by linear_c1 itself (zero weight rows / bias entries behind the real ones) and meet zero weight
+    # columns in low_level_fuse, so that GEMM runs on the 256-row tile kernels (K % 64 == 0)
+    c1 = P['linear_c1.proj.weight'].shape[0]
+    Kc = (E + c1 + 63) // 64 * 64
+    cat2f = torch.empty((R4, Kc), dtype=T, device=dev)
+    cat2 = cat2f[:, :E + c1]
     ops.bn_apply_up(z8, B, H8, W8, H4, W4, stc, P['cat.bn.weight'], P['cat.bn.bias'], act=1, out=cat2[:, :E], bvec=vb)
-    ops.gemm_nt(t[0], w_fwd(P['linear_c1.proj.weight'], T), bias=P['linear_c1.proj.bias'], out=cat2[:, E:])
-    zl, stl = _conv_bn_stats(cat2, _conv_w(P['low_level_fuse.conv.weight'], T), P, Bf, 'low_level_fuse.bn', training)
+    ops.gemm_nt(t[0], weightprep.cast_padded(P['linear_c1.proj.weight'], T, Kc - E), bias=weightprep.cast_padded(P['linear_c1.proj.bias'], torch.float32, Kc - E).view(-1),
+                out=cat2f[:, E:])
+    zl, stl = _conv_bn_stats(cat2f, weightprep.pack(P['low_level_fuse.conv.weight'], T, k_multiple=64), P, Bf, 'low_level_fuse.bn', training)
     nc = P['linear_pred.weight'].shape[0]
     rpi4 = H4 * W4 if drop_mask is not None else 0
     if ops.bn_classify_ok(E, nc):
@@ -208,7 +222,7 @@ def head_backward(P, S, dseg, E):
                               rows_per_image=rpi4, training=training)
     bn_grads('low_level_fuse.bn', dgb)
     G['low_level_fuse.conv.weight'] = ops.gemm_tn(dzl, S['cat2'])
-    dcat2 = ops.gemm_nt(dzl, w_bwd(P['low_level_fuse.conv.weight'], T))
+    dcat2 = ops.gemm_nt(dzl, w_bwd(P['low_level_fuse.conv.weight'], T), out=_rows_on_lines(dzl.shape[0], S['cat2'].shape[1], T, dzl.device))
     dc1 = dcat2[:, E:]
     G['linear_c1.proj.weight'], G['linear_c1.proj.bias'] = ops.gemm_tn(dc1, t[0], colsum=True)
     dt = [ops.gemm_nt(dc1, w_bwd(P['linear_c1.proj.weight'], T)), None, None, None]

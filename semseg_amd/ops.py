@@ -699,12 +699,15 @@ def transpose_cast(w, dtype, reverse_cols=False):
     return out
 
 
-def pack_conv_weight(w, dtype, transposed=True):
-    """fp32 conv weight [O, I, k, k] -> packed [O, Kp] (ky,kx,i order, zero padded) and its transpose [Kp, O]."""
+def pack_conv_weight(w, dtype, transposed=True, k_multiple=8):
+    """fp32 conv weight [O, I, k, k] -> packed [O, Kp] (ky,kx,i order, zero padded) and its transpose [Kp, O];
+    Kp = k*k*I rounded up to k_multiple (a multiple of 8)."""
     _dev(w)
     O, I, k, k2 = w.shape
     _f32(w, 'w')
-    Kp = (k * k * I + 7) // 8 * 8
+    if k_multiple <= 0 or k_multiple % 8:
+        raise ValueError('pack_conv_weight: k_multiple must be a positive multiple of 8')
+    Kp = (k * k * I + k_multiple - 1) // k_multiple * k_multiple
     wp = torch.empty((O, Kp), dtype=dtype, device=w.device)
     wpt = torch.empty((Kp, O), dtype=dtype, device=w.device) if transposed else None
     check(lib().ss_pack_conv_weight(_DT[dtype], _p(w), _p(wp), _p(wpt), O, I, k, Kp, _stream()))

@@ -170,18 +170,40 @@ def transpose_padded(p, rows, cols, dtype, pad_rows):
     return _PADDED[out.data_ptr()]
 
 
-def pack(p, dtype, transposed=False):
-    """Conv weight [O, I, k, k] -> packed GEMM operand [O, Kp] (or its transpose [Kp, O]), column order (ky, kx, i), zero padded."""
+def pack(p, dtype, transposed=False, k_multiple=8):
+    """Conv weight [O, I, k, k] -> packed GEMM operand [O, Kp] (or its transpose [Kp, O]), column order (ky, kx, i), zero padded
+    to a multiple of k_multiple columns."""
     if not isinstance(p, nn.Parameter):
-        wp, wpt = ops.pack_conv_weight(p.detach(), dtype, transposed=transposed)
+        wp, wpt = ops.pack_conv_weight(p.detach(), dtype, transposed=transposed, k_multiple=k_multiple)
         return wpt if transposed else wp
     O, I, k, _ = p.shape
-    Kp = (k * k * I + 7) // 8 * 8
+    Kp = (k * k * I + k_multiple - 1) // k_multiple * k_multiple
 
     def make():
         v = p.detach()
         if not v.is_contiguous() or v.dtype != torch.float32:
             raise ValueError('semseg_amd: parameters must be contiguous float32')
-        wp, wpt = ops.pack_conv_weight(v, dtype, transposed=transposed)
+        wp, wpt = ops.pack_conv_weight(v, dtype, transposed=transposed, k_multiple=k_multiple)
         return v, (wpt if transposed else wp), ((3 if transposed else 2, 0), O, I, k | (Kp << 32))
-    return _lookup(p, ('pack', dtype, bool(transposed)), make)
+    return _lookup(p, ('pack', dtype, bool(transposed), k_multiple), make)
+
+
+def cast_padded(p, dtype, pad_rows):
+    """``cast`` whose [rows, cols] result is the head of a persistent [pad_rows, cols] buffer with zero rows behind it (a Linear that
+    writes a few always-zero output columns: the padding of a concat buffer to whole k-tiles).  -> the padded buffer."""
+    rows = p.shape[0]
+    cols = p.numel() // rows
+    if not isinstance(p, nn.Parameter):
+        full = torch.zeros((pad_rows, cols), dtype=dtype, device=p.device)
+        full[:rows] = p.detach().reshape(rows, cols).to(dtype)
+        return full
+
+    def make():
+        v = _view2d(p, rows, cols)
+        full = torch.zeros((pad_rows, cols), dtype=dtype, device=p.device)
+        out = full[:rows]
+        check(lib().ss_cast(0, ops._DT[dtype], v.data_ptr(), out.data_ptr(), rows * cols, torch.cuda.current_stream(p.device).cuda_stream))
+        _PADDED[out.data_ptr()] = full
+        return v, out, ((0, 0), 0, 0, 0)
+    out = _lookup(p, ('castp', dtype, pad_rows), make)
+    return _PADDED[out.data_ptr()]
