@@ -132,10 +132,14 @@ int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* x, int64_t 
                  float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
 /* The x2 case (ho = 2 hi, wo = 2 wi) with the transpose of the resize folded into the second pass: returns
- * dx [B*hi*wi, C] = ss_bilinear_bwd(dz) and never writes dz (same weights; the sums run in another order). */
+ * dx [B*hi*wi, C] = ss_bilinear_bwd(dz) and never writes dz (same weights; the sums run in another order).
+ * g_scratch (optional, [B*ho*wo, C] with row pitch ldg in the compute dtype; MAY BE dy itself when the caller no longer needs dy):
+ * with act = 1 the first pass leaves g = dy * Mish'(.) there and the second pass reads it instead of evaluating the derivative a
+ * second time (g is rounded to the compute dtype, as a separately stored activation gradient would be). */
 int ss_bn_bwd_up2_dx(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi,
                      const float* stats, const float* gamma, const float* beta, int training, void* dx, int64_t ldo,
-                     float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
+                     float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, void* g_scratch, int64_t ldg,
+                     hipStream_t stream);
 
 /* LawinHead's tail seg = linear_pred(dropout(low_level_fuse's Mish(BatchNorm(z)))) (modules/lawin.py:101-105,227-228) without the
  * E-channel activation in memory.  wp [nc, C] / bp [nc] are the classifier's fp32 parameters (nc <= 8; C = 8 * a power of two,

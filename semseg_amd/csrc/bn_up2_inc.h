@@ -237,9 +237,14 @@ __global__ __launch_bounds__(256) void bn_bwd_up2_kernel(const T* __restrict__ d
                         float gg = d[r][col].get(e);
                         if (ACT == 1) gg *= mish_grad(fmaf(xh, gm.v[e], bt.v[e]));
                         if (PASS2) o.v[e] = fmaf(k0.v[e], gg, fmaf(xh, k2.v[e], k1.v[e]));
-                        else if (live) { acc[0][e] += gg; acc[1][e] = fmaf(gg, xh, acc[1][e]); }
+                        else {
+                            // pass 1 with a destination: g = dy * act'(.) is kept (rounded to the storage dtype, and summed as
+                            // rounded) so that the second pass does not evaluate the activation's derivative again
+                            if (dz) { gg = (float)(T)gg; o.v[e] = gg; }
+                            if (live) { acc[0][e] += gg; acc[1][e] = fmaf(gg, xh, acc[1][e]); }
+                        }
                     }
-                    if (PASS2 && live) storeN(zb + ((int64_t)(2 * p + r) * wo + col) * ldo, o);
+                    if ((PASS2 || dz) && live) storeN(zb + ((int64_t)(2 * p + r) * wo + col) * ldo, o);
                 }
         });
     }

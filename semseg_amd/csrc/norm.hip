@@ -726,7 +726,7 @@ extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* 
         const int nb = up2_blocks(u, B);
         dim3 g1((unsigned)nb, (unsigned)u.groups), g2((unsigned)(B * u.xtiles * u.ystrips), (unsigned)u.groups);
 #define SS_BN_BWD_UP2(ACT, P2, GRID) hipLaunchKernelGGL((bn_bwd_up2_kernel<T, ACT, P2>), GRID, dim3(256), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, \
-        bvec, B, hi, wi, stats, gamma, beta, coef, (T*)dz, ldo, workspace, C, u)
+        bvec, B, hi, wi, stats, gamma, beta, coef, P2 ? (T*)dz : (T*)nullptr, ldo, workspace, C, u)
         SS_DISPATCH(dtype, {
             if (act) SS_BN_BWD_UP2(1, false, g1); else SS_BN_BWD_UP2(0, false, g1);
             SS_LAUNCH_CHECK();
@@ -753,8 +753,11 @@ extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* 
 // x2 only: pass 1 as ss_bn_bwd_up, pass 2 returns dx [B*hi*wi, C] = ss_bilinear_bwd(dz) directly (dz is never written)
 extern "C" int ss_bn_bwd_up2_dx(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi,
                                 const float* stats, const float* gamma, const float* beta, int training, void* dx, int64_t ldo,
-                                float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream) {
+                                float* dgamma_dbeta, int C, int act, float* workspace, int64_t ws_bytes, void* g_scratch, int64_t ldg,
+                                hipStream_t stream) {
     SS_CHECK(dy && x && stats && gamma && beta && dx && dgamma_dbeta && workspace && C > 0 && C % 8 == 0, "ss_bn_bwd_up2_dx: bad arguments");
+    SS_CHECK(!g_scratch || (ldg >= C && ldg % 8 == 0 && aligned16(g_scratch) && g_scratch != dx), "ss_bn_bwd_up2_dx: bad g_scratch");
+    if (!act) g_scratch = nullptr;                         // nothing to keep: g is dy
     SS_CHECK(ldd >= C && ldx >= C && ldo >= C && ldd % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && aligned16(dy) && aligned16(x) && aligned16(dx),
              "ss_bn_bwd_up2_dx: bad leading dimensions");
     SS_CHECK(act == 0 || act == 1, "ss_bn_bwd_up2_dx: act must be 0 (none) or 1 (Mish)");
@@ -771,13 +774,15 @@ extern "C" int ss_bn_bwd_up2_dx(int dtype, const void* dy, int64_t ldd, const vo
     dim3 g1((unsigned)nb, (unsigned)u.groups), g2((unsigned)(B * u2.xtiles * u2.ystrips), (unsigned)u2.groups);
     SS_DISPATCH(dtype, {
         if (act) hipLaunchKernelGGL((bn_bwd_up2_kernel<T, 1, false>), g1, dim3(256), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, bvec, B, hi, wi, stats, gamma, beta,
-                                    coef, (T*)nullptr, (int64_t)0, workspace, C, u);
+                                    coef, (T*)g_scratch, ldg, workspace, C, u);
         else hipLaunchKernelGGL((bn_bwd_up2_kernel<T, 0, false>), g1, dim3(256), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, bvec, B, hi, wi, stats, gamma, beta,
                                 coef, (T*)nullptr, (int64_t)0, workspace, C, u);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, nb, C, rows, training, dgamma_dbeta, coef);
         SS_LAUNCH_CHECK();
-        if (act) hipLaunchKernelGGL((bn_bwd_up2_dx_kernel<T, 1>), g2, dim3(512), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, bvec, hi, wi, stats, gamma, beta, coef,
+        if (act && g_scratch) hipLaunchKernelGGL((bn_bwd_up2_dx_kernel<T, 0>), g2, dim3(512), 0, stream, (const T*)g_scratch, ldg, (const T*)x, ldx, bvec, hi, wi, stats,
+                                                 gamma, beta, coef, (T*)dx, ldo, C, u2);
+        else if (act) hipLaunchKernelGGL((bn_bwd_up2_dx_kernel<T, 1>), g2, dim3(512), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, bvec, hi, wi, stats, gamma, beta, coef,
                                     (T*)dx, ldo, C, u2);
         else hipLaunchKernelGGL((bn_bwd_up2_dx_kernel<T, 0>), g2, dim3(512), 0, stream, (const T*)dy, ldd, (const T*)x, ldx, bvec, hi, wi, stats, gamma, beta, coef,
                                 (T*)dx, ldo, C, u2);

@@ -228,7 +228,7 @@ def head_backward(P, S, dseg, E):
     dt = [ops.gemm_nt(dc1, w_bwd(P['linear_c1.proj.weight'], T)), None, None, None]
     # cat
     dz8, dgb = ops.bn_bwd_up_to_input(dcat2[:, :E], S['z8'], B, H8, W8, H4, W4, S['stc'], P['cat.bn.weight'], P['cat.bn.bias'], act=1,
-                                      training=training, bvec=S['vb'])
+                                      training=training, bvec=S['vb'], overwrite_dy=True)
     bn_grads('cat.bn', dgb)
     Gc = torch.empty((E, 5 * E), dtype=torch.float32, device=dz8.device)
     G['cat.conv.weight'] = Gc

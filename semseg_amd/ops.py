@@ -553,8 +553,9 @@ def bn_bwd_up(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True
     return out, dgb
 
 
-def bn_bwd_up_to_input(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True, bvec=None):
-    """bilinear_bwd(bn_bwd_up(...)[0]) -> dx [B*hi*wi, C], dgb [2,C]; for the x2 resize the gradient of the resized map is never written."""
+def bn_bwd_up_to_input(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, training=True, bvec=None, overwrite_dy=False):
+    """bilinear_bwd(bn_bwd_up(...)[0]) -> dx [B*hi*wi, C], dgb [2,C]; for the x2 resize the gradient of the resized map is never written.
+    overwrite_dy: the caller is done with dy -- the first pass may leave dy * act'(.) in it for the second pass (x2 resize, act = 1)."""
     if (ho, wo) != (2 * hi, 2 * wi):
         dz, dgb = bn_bwd_up(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=act, training=training, bvec=bvec)
         return bilinear_bwd(dz, B, hi, wi, ho, wo), dgb
@@ -569,7 +570,8 @@ def bn_bwd_up_to_input(dy, x, B, hi, wi, ho, wo, stats, gamma, beta, act=0, trai
     dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
     ws = workspace(dev, (COLRED_BLOCKS * 2 * C + 2 * C) * 4)
     check(lib().ss_bn_bwd_up2_dx(dt(x), _p(dy), ldd, _p(x), ldx, _p(bvec), B, hi, wi, _p(stats), _p(gamma), _p(beta), int(training),
-                                 _p(dx), C, _p(dgb), C, act, _p(ws), ws.numel(), _stream()))
+                                 _p(dx), C, _p(dgb), C, act, _p(ws), ws.numel(), _p(dy) if overwrite_dy else None, ldd if overwrite_dy else 0,
+                                 _stream()))
     return dx, dgb
 
 

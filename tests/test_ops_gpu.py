@@ -279,6 +279,15 @@ def test_batchnorm_of_bilinear_resize(ops, dtype, B, hi, wi, ho, wo, C, act):
     # second pass with the transpose of the resize folded in (x2), the unfused pair otherwise
     dx2, dgb5 = ops.bn_bwd_up_to_input(dyd, xd, B, hi, wi, ho, wo, st1, dev(g), dev(b), act)
     assert rel(dx2, xr.grad) < _gtol(dtype) and rel(dx2, dx) < (1e-5 if dtype == torch.float32 else 8e-3) and rel(dgb5, dgb2) < 1e-6
+    # the same with dy given up as scratch: pass 1 leaves dy * act'(.) in it (rounded to the storage dtype), pass 2 reads that
+    scratch = torch.full((B * ho * wo, C + 16), 7.0, dtype=dtype, device='cuda')
+    scratch[:, 8:8 + C] = dyd
+    dx6, dgb6 = ops.bn_bwd_up_to_input(scratch[:, 8:8 + C], xd, B, hi, wi, ho, wo, st1, dev(g), dev(b), act, overwrite_dy=True)
+    assert rel(dx6, xr.grad) < _gtol(dtype) and rel(dx6, dx2) < (1e-6 if dtype == torch.float32 else 8e-3)
+    assert rel(dgb6, dgb5) < (1e-6 if dtype == torch.float32 else 2e-3)
+    assert float((scratch[:, :8] - 7).abs().max()) == 0 and float((scratch[:, 8 + C:] - 7).abs().max()) == 0
+    if not act or (ho, wo) != (2 * hi, 2 * wi):
+        assert torch.equal(scratch[:, 8:8 + C], dyd)          # nothing to keep: dy is left alone
     # eval mode
     st3 = ops.bn_eval_stats(dev(rm), dev(rv))
     y3 = ops.bn_apply_up(xd, B, hi, wi, ho, wo, st3, dev(g), dev(b), act)
