@@ -538,7 +538,7 @@ def test_conv_patch_ok_rejects_what_the_patch_gemm_cannot_address(ops):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('hi,wi,ho,wo,C', [(4, 4, 16, 16, 64), (8, 6, 16, 12, 16), (16, 16, 64, 64, 6), (5, 7, 13, 9, 8), (1, 1, 8, 8, 32),
-                                           (32, 40, 128, 160, 6), (7, 9, 20, 31, 5), (16, 300, 8, 150, 6), (3, 3, 9, 9, 2), (1, 5, 4, 20, 6), (9, 300, 18, 600, 3), (2, 1, 8, 4, 8)])
+                                           (32, 40, 128, 160, 6), (7, 9, 20, 31, 5), (16, 300, 8, 150, 6), (3, 3, 9, 9, 2), (1, 5, 4, 20, 6), (9, 300, 18, 600, 3), (2, 1, 8, 4, 8), (4, 300, 16, 1200, 6), (3, 257, 6, 514, 4)])
 def test_bilinear(ops, dtype, hi, wi, ho, wo, C):
     B = 2
     x = rnd(B, C, hi, wi)
