@@ -328,7 +328,9 @@ int ss_fast_tn_launch(FastGemm p, int nsplit, hipStream_t st) {
 
 // The same tile kernels with one operand addressed as image patches (PatchMap): the convolutions with kernel = stride.
 int ss_patch_nt_launch(FastGemm p, hipStream_t st) {
-    const bool narrow = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 1024);
+    // fewer 128-column tiles than CUs (the spatial-reduction convs: 16384 patches x 128 channels = 128 tiles, k-loops of 32-64
+    // iterations): 64-column tiles put twice as many workgroups on the chip; the second read of the patch rows comes from L2
+    const bool narrow = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 1024) || cdiv(p.N, 128) * cdiv(p.M, 128) < 256;
     if (narrow) {
         p.ntn = (int)cdiv(p.N, 64);
         hipLaunchKernelGGL((gemm_nt_bf16_kernel<64, true>), dim3((unsigned)(p.ntn * cdiv(p.M, 128))), dim3(256), 0, st, p);
