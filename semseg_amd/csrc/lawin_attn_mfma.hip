@@ -9,6 +9,14 @@
 // from the forward's base-2 log-sum-exp.  Outputs leave as 8-byte pieces of 4 consecutive channels per lane.
 #include "attn_common.h"
 
+// Workgroups b, b + 8, ... run on one XCD (one L2).  The waves of a window's heads read 32-128-byte slices of the same rows: handing
+// each XCD a CONTIGUOUS run of (window, head) pairs keeps every 128-byte line in one L2 instead of fetching it into several
+// (FETCH_SIZE of the d = 4 / d = 16 backward kernels was 3x the operand bytes with the round-robin order).
+__device__ __forceinline__ unsigned xcd_block() {
+    const unsigned n = gridDim.x, q = n >> 3, r = n & 7, x = blockIdx.x & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+}
+
 struct LawinAttnArgs {
     const bf16 *theta, *pg, *y, *dy; const float* lse; bf16 *out, *dtheta, *dpg; float* lse_out;
     int64_t ldt, ldy, lddy, lddt;
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(128) void lawin_attn_fwd_mfma_kernel(LawinAttnArgs 
     constexpr int KS = G::KS, TD = G::TD, PT = G::PT;
     __shared__ __attribute__((aligned(16))) char smem[2 * G::IMG];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int64_t idx = (int64_t)blockIdx.x * 2 + wave;
+    const int64_t idx = (int64_t)xcd_block() * 2 + wave;
     if (idx >= a.nwin * a.heads) return;
     const int64_t wi = idx / a.heads; const int hd = (int)(idx % a.heads);
     char* Vt = smem + wave * G::IMG;
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(128) void lawin_attn_bwd_mfma_kernel(LawinAttnArgs 
     constexpr int PER_WAVE = 2 * G::IMG + 512;
     __shared__ __attribute__((aligned(16))) char smem[2 * PER_WAVE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int64_t idx = (int64_t)blockIdx.x * 2 + wave;
+    const int64_t idx = (int64_t)xcd_block() * 2 + wave;
     if (idx >= a.nwin * a.heads) return;
     const int64_t wi = idx / a.heads; const int hd = (int)(idx % a.heads);
     char* R0 = smem + wave * PER_WAVE; char* R1 = R0 + G::IMG; float* lsd = (float*)(R1 + G::IMG);     // lse[64] | delta[64]
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(128) void lawin_attn_fwd_grp_kernel(LawinAttnArgs a
     __shared__ __attribute__((aligned(16))) char smem[2 * C::IMG];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int groups = a.heads / G;
-    const int64_t idx = (int64_t)blockIdx.x * 2 + wave;
+    const int64_t idx = (int64_t)xcd_block() * 2 + wave;
     if (idx >= a.nwin * groups) return;
     const int64_t wi = idx / groups; const int gp = (int)(idx % groups);
     char* Vt = smem + wave * C::IMG;
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(128) void lawin_attn_bwd_grp_kernel(LawinAttnArgs a
     __shared__ __attribute__((aligned(16))) char smem[2 * PER_WAVE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int groups = a.heads / G;
-    const int64_t idx = (int64_t)blockIdx.x * 2 + wave;
+    const int64_t idx = (int64_t)xcd_block() * 2 + wave;
     if (idx >= a.nwin * groups) return;
     const int64_t wi = idx / groups; const int gp = (int)(idx % groups);
     char* R0 = smem + wave * PER_WAVE; char* R1 = R0 + C::IMG; float* lsd = (float*)(R1 + C::IMG);     // [G][ lse[64] | delta[64] ]
