@@ -90,12 +90,29 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(FastGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // the residual tile rides in the staging registers during the LAST k-iteration (they are free then): its HBM round trip
+    // overlaps that iteration's MFMAs instead of standing between the k-loop and the epilogue
+    constexpr int CPR = BN / 8;                        // 16-byte chunks per tile row
+    constexpr int RPP = 256 / CPR;                     // rows per pass
+    static_assert(BM / RPP <= 4 + NB, "residual tile does not fit the staging registers");
+    const int erow = tid / CPR, ech = tid % CPR;
+    const bool ncol_ok = n0 + ech * 8 < p.N;
+    auto rload = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < BM / RPP; ++ps) {
+            const int row = ps * RPP + erow;
+            const bf16x8 v = (m0 + row < p.M && ncol_ok) ? *(const bf16x8*)(p.res + (m0 + row) * p.ldr + n0 + ech * 8) : zero;
+            if (ps < 4) ra[ps & 3] = v; else rb[(ps - 4) & (NB - 1)] = v;
+        }
+    };
+
     gload(0);
     lstore();
     __syncthreads();
     for (int k0 = 0; k0 < K; k0 += BK) {
         const bool more = k0 + BK < K;
         if (more) gload(k0 + BK);
+        else if (p.res) rload();
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 fa[2], fb[TN];
@@ -115,16 +132,11 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_kernel(FastGemm p) {
 
     // ---- epilogue through an LDS [m][n] image (pitch EP bytes)
     bf16* C = (bf16*)p.C;
-    constexpr int CPR = BN / 8;                        // 16-byte chunks per tile row
-    constexpr int RPP = 256 / CPR;                     // rows per pass
-    const int erow = tid / CPR, ech = tid % CPR;
-    const bool ncol_ok = n0 + ech * 8 < p.N;
     if (p.res) {
 #pragma unroll
         for (int ps = 0; ps < BM / RPP; ++ps) {
-            int row = ps * RPP + erow;
-            if (m0 + row < p.M && ncol_ok)
-                *(bf16x8*)(smem + row * EP + ech * 16) = *(const bf16x8*)(p.res + (m0 + row) * p.ldr + n0 + ech * 8);
+            const int row = ps * RPP + erow;
+            *(bf16x8*)(smem + row * EP + ech * 16) = ps < 4 ? ra[ps & 3] : rb[(ps - 4) & (NB - 1)];
         }
         __syncthreads();
     }
