@@ -23,6 +23,9 @@ def _convert_all(ps, wp, dtype):
         if p.dim() == 4 and p.shape[1] > 1:
             out.append(wp.pack(p, dtype))
             out.append(wp.pack(p, dtype, transposed=True))
+            out.append(wp.pack(p, dtype, k_multiple=64))      # zero columns up to whole 64-column k-tiles
+        if p.dim() == 2:
+            out.append(wp.cast_padded(p, dtype, (n + 63) // 64 * 64))    # zero rows behind the real ones
     return out
 
 
@@ -43,6 +46,15 @@ def test_batched_refresh_equals_single_tensor_kernels(dtype):
     want = _convert_all(ps, wp, dtype)                        # fresh single-tensor conversions of the new values
     for g, w in zip(got, want):
         assert g.dtype == w.dtype and g.shape == w.shape and torch.equal(g, w)
+    # the padded forms: real part = the plain conversion, padding exactly zero
+    for p in ps:
+        n = p.shape[0]
+        if p.dim() == 2:
+            full = wp.cast_padded(p, dtype, (n + 63) // 64 * 64)
+            assert full.shape[0] % 64 == 0 and torch.equal(full[:n], wp.cast(p, dtype)) and float(full[n:].abs().sum()) == 0
+        if p.dim() == 4 and p.shape[1] > 1:
+            wide, base = wp.pack(p, dtype, k_multiple=64), wp.pack(p, dtype)
+            assert wide.shape[1] % 64 == 0 and torch.equal(wide[:, :base.shape[1]], base) and float(wide[:, base.shape[1]:].abs().sum()) == 0
     # writes through .data do not move the version counter: bump() is the contract
     wp.cast(ps[0], torch.bfloat16)
     ps[0].data.zero_()
