@@ -35,10 +35,13 @@ def _p(t):
 
 
 def workspace(device, nbytes):
-    t = _WS.get(device)
+    """scratch for the entry point about to be launched: one buffer per (device, stream) -- launches on one stream run in order, so
+    they can share it; two streams (runtime.side_stream) must not"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 64 << 20), dtype=torch.uint8, device=device)
-        _WS[device] = t
+        _WS[key] = t
     return t
 
 
