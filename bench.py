@@ -127,6 +127,8 @@ def entry_work(name, a):
     if name in ('ss_bilinear_fwd', 'ss_bilinear_fwd_add'):
         B, hi, wi, ho, wo, C = a[5:11]
         return 'hbm', 1.0 * B * C * (hi * wi + ho * wo) * _sz(a[0])
+    if name == 'ss_bilinear_fwd2':       # (dtype, x, ldx, hi, wi, x2, ldx2, hi2, wi2, y, ldy, B, ho, wo, C)
+        return 'hbm', 1.0 * a[11] * a[14] * (a[3] * a[4] + a[7] * a[8] + a[12] * a[13]) * _sz(a[0])
     if name == 'ss_bilinear_bwd':
         B, hi, wi, ho, wo, C = a[5:11]
         return 'hbm', 1.0 * B * C * (hi * wi + ho * wo) * _sz(a[0])

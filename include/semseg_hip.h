@@ -235,6 +235,10 @@ int ss_bilinear_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy,
  * (modules/lawin.py:183-199), with the conv commuted below the resize */
 int ss_bilinear_fwd_add(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
                         hipStream_t stream);
+/* y = resize(x) + resize(x2) in one pass (LawinHead.linear_fuse run per level: up(c4-part) + up(c3-part), modules/lawin.py:183-199);
+ * the sum is formed in fp32 and rounded once.  C % 8 == 0. */
+int ss_bilinear_fwd2(int dtype, const void* x, int64_t ldx, int hi, int wi, const void* x2, int64_t ldx2, int hi2, int wi2,
+                     void* y, int64_t ldy, int B, int ho, int wo, int C, hipStream_t stream);
 int ss_bilinear_bwd(int dtype, const void* dy, int64_t ldy, void* dx, int64_t ldx, int B, int hi, int wi, int ho, int wo, int C,
                     int accumulate, hipStream_t stream);
 

@@ -139,9 +139,11 @@ extern "C" int ss_col2im(int dtype, const void* col, void* dx, int B, int H, int
 
 // ------------------------------------------------------------------ bilinear (align_corners = False), torch semantics
 // grid: (B*ho output rows, blocks over the wo * chunks items of a row); the vertical tap is uniform per workgroup
+// (x2: an optional second source of its own size; the two interpolated values are added in fp32 and rounded once)
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
-        int hi, int wi, int ho, int wo, FastDiv dchunks, int accumulate) {
+        int hi, int wi, int ho, int wo, FastDiv dchunks, int accumulate, const T* __restrict__ x2 = nullptr, int64_t ldx2 = 0,
+        int hi2 = 0, int wi2 = 0) {
     constexpr int W8 = VEC ? 8 : 1;
     const unsigned chunks = dchunks.d;
     const unsigned idx = blockIdx.y * 256u + threadIdx.x;
@@ -156,6 +158,14 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
         F8 a = load8(r0 + tx.i0 * ldx), bq = load8(r0 + tx.i1 * ldx), cq = load8(r1 + tx.i0 * ldx), d = load8(r1 + tx.i1 * ldx), o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.v[e] = bilerp(ty, tx, a.v[e], bq.v[e], cq.v[e], d.v[e]);
+        if (x2) {
+            const LinTap uy = lin_tap((int)oy, (float)hi2 / ho, hi2), ux = lin_tap((int)ox, (float)wi2 / wo, wi2);
+            const T* s0 = x2 + (((int64_t)b * hi2 + uy.i0) * wi2) * ldx2 + c;
+            const T* s1 = x2 + (((int64_t)b * hi2 + uy.i1) * wi2) * ldx2 + c;
+            const F8 a2 = load8(s0 + ux.i0 * ldx2), b2 = load8(s0 + ux.i1 * ldx2), c2 = load8(s1 + ux.i0 * ldx2), d2 = load8(s1 + ux.i1 * ldx2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] += bilerp(uy, ux, a2.v[e], b2.v[e], c2.v[e], d2.v[e]);
+        }
         if (accumulate) { const F8 p = load8(dst);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o.v[e] += p.v[e]; }
@@ -390,6 +400,20 @@ extern "C" int ss_bilinear_fwd(int dtype, const void* x, int64_t ldx, void* y, i
 extern "C" int ss_bilinear_fwd_add(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int hi, int wi, int ho, int wo, int C,
                                    hipStream_t stream) {
     return bilinear_fwd_impl(dtype, x, ldx, y, ldy, B, hi, wi, ho, wo, C, 1, stream);
+}
+// y = resize(x) + resize(x2): two maps of different sizes brought to one size and summed in one pass (one rounding)
+extern "C" int ss_bilinear_fwd2(int dtype, const void* x, int64_t ldx, int hi, int wi, const void* x2, int64_t ldx2, int hi2, int wi2,
+                                void* y, int64_t ldy, int B, int ho, int wo, int C, hipStream_t stream) {
+    SS_CHECK(x && x2 && y && B > 0 && hi > 0 && wi > 0 && hi2 > 0 && wi2 > 0 && ho > 0 && wo > 0 && C > 0, "ss_bilinear_fwd2: bad arguments");
+    SS_CHECK(C % 8 == 0 && ldx >= C && ldx2 >= C && ldy >= C && ldx % 8 == 0 && ldx2 % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(x2) && aligned16(y),
+             "ss_bilinear_fwd2: C and the leading dimensions must be multiples of 8, pointers 16-byte aligned");
+    const int64_t per_row = (int64_t)wo * (C / 8);
+    SS_CHECK(per_row < (1LL << 31) && cdiv(per_row, 256) < 65536 && (int64_t)B * ho < (1LL << 31), "ss_bilinear_fwd2: row too long");
+    dim3 grid((unsigned)(B * ho), (unsigned)cdiv(per_row, 256));
+    SS_DISPATCH(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)x, ldx, (T*)y, ldy, hi, wi, ho, wo,
+                                          fast_div(C / 8), 0, (const T*)x2, ldx2, hi2, wi2));
+    SS_LAUNCH_CHECK();
+    return 0;
 }
 extern "C" int ss_bilinear_class_map_u8(int dtype, const void* x, int64_t ldx, uint8_t* out, int B, int hi, int wi, int ho, int wo, int C,
                                         hipStream_t stream) {

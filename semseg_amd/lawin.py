@@ -133,10 +133,12 @@ def head_forward(P, Bf, feats, E, training, drop_mask):
     # and summed -- no [R8, 3E] concat, 1/16 and 1/4 of the conv's work for c4 and c3 (exact in real arithmetic, rounding reordered)
     Wf = _conv_w(P['linear_fuse.conv.weight'], T)
     cl = [None] + [ops.gemm_nt(t[lvl], w_fwd(P[f'linear_c{lvl + 1}.proj.weight'], T), bias=P[f'linear_c{lvl + 1}.proj.bias']) for lvl in (1, 2, 3)]
-    U = None
-    for lvl, sl in ((2, slice(E, 2 * E)), (3, slice(0, E))):
-        gl = ops.gemm_nt(cl[lvl], Wf[:, sl])
-        U = ops.bilinear_fwd(gl, B, hw[lvl][0], hw[lvl][1], H8, W8, out=U, accumulate=U is not None)
+    g2, g3 = ops.gemm_nt(cl[2], Wf[:, E:2 * E]), ops.gemm_nt(cl[3], Wf[:, :E])
+    if E % 8 == 0:
+        U = ops.bilinear_fwd2(g2, hw[2][0], hw[2][1], g3, hw[3][0], hw[3][1], B, H8, W8)       # both levels in one pass over U
+    else:
+        U = ops.bilinear_fwd(g2, B, hw[2][0], hw[2][1], H8, W8)
+        U = ops.bilinear_fwd(g3, B, hw[3][0], hw[3][1], H8, W8, out=U, accumulate=True)
     zf, stf = _conv_bn_stats(cl[1], Wf[:, 2 * E:], P, Bf, 'linear_fuse.bn', training, res=U)
     cat5 = torch.empty((R8, 4 * E), dtype=T, device=dev)          # [feat, z_8, z_4, z_2] (conv_out outputs); the pooled branch is a vector per image
     feat = ops.bn_apply(zf, stf, P['linear_fuse.bn.weight'], P['linear_fuse.bn.bias'], act=1, out=cat5[:, :E])

@@ -453,6 +453,18 @@ def conv_patch_wgrad(dy, x, B, H, W, C, s, want_bias=True):
     return dw, db
 
 
+def bilinear_fwd2(x, hi, wi, x2, hi2, wi2, B, ho, wo):
+    """resize(x [B*hi*wi, C]) + resize(x2 [B*hi2*wi2, C]) -> [B*ho*wo, C], summed in fp32 and rounded once"""
+    dev = _dev(x)
+    r, C, ldx = _mat(x, 'x')
+    r2, C2, ldx2 = _mat(x2, 'x2')
+    if r != B * hi * wi or r2 != B * hi2 * wi2 or C != C2 or x.dtype != x2.dtype or C % 8:
+        raise ValueError('bilinear_fwd2: shapes do not match (C must be a multiple of 8)')
+    out = torch.empty((B * ho * wo, C), dtype=x.dtype, device=dev)
+    check(lib().ss_bilinear_fwd2(dt(x), _p(x), ldx, hi, wi, _p(x2), ldx2, hi2, wi2, _p(out), C, B, ho, wo, C, _stream()))
+    return out
+
+
 def bilinear_fwd(x, B, hi, wi, ho, wo, out=None, accumulate=False):
     """x [B*hi*wi, C] (row stride ld) -> out [B*ho*wo, C] (may be a channel slice of a wider buffer); accumulate: out += resize(x)."""
     dev = _dev(x)

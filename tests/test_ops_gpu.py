@@ -555,6 +555,23 @@ def test_bilinear(ops, dtype, hi, wi, ho, wo, C):
     assert rel(dx.view(B, hi, wi, C), xr.grad.permute(0, 2, 3, 1)) < _tol(dtype)
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_bilinear_two_sources(ops, dtype):
+    """ss_bilinear_fwd2 = resize(a) + resize(b) of two map sizes in one pass, against torch and against the two-pass form"""
+    B, C, ho, wo = 2, 24, 16, 24
+    a, b = rnd(B, C, 4, 6), rnd(B, C, 8, 12, seed=1)
+    ref = (F.interpolate(q(a, dtype), size=(ho, wo), mode='bilinear', align_corners=False)
+           + F.interpolate(q(b, dtype), size=(ho, wo), mode='bilinear', align_corners=False)).permute(0, 2, 3, 1).reshape(-1, C)
+    ad = dev(a.permute(0, 2, 3, 1).reshape(-1, C).contiguous(), dtype)
+    bd = dev(b.permute(0, 2, 3, 1).reshape(-1, C).contiguous(), dtype)
+    y = ops.bilinear_fwd2(ad, 4, 6, bd, 8, 12, B, ho, wo)
+    assert rel(y, ref) < _tol(dtype)
+    two = ops.bilinear_fwd(bd, B, 8, 12, ho, wo, out=ops.bilinear_fwd(ad, B, 4, 6, ho, wo), accumulate=True)
+    assert rel(y, two) < (1e-6 if dtype == torch.float32 else 8e-3)
+    with pytest.raises(ValueError):
+        ops.bilinear_fwd2(ad[:, :20], 4, 6, bd[:, :20], 8, 12, B, ho, wo)
+
+
 def test_small_helpers(ops):
     x = rnd(64, 32)
     xb = ops.cast(dev(x), torch.bfloat16)
