@@ -321,7 +321,7 @@ static inline DwFGeom dwf_geom(int B, int H, int W, int C, int ne) {
     // XL columns per workgroup, XL - 2 of them produce output: wide enough to keep the halo share small, narrow enough that the
     // chunk lanes of one image column still cover whole 128-byte lines where C allows it
     int xl = 32;
-    while (xl > 8 && (256 / xl) * 2 <= g.chunks && (256 / xl) * ne * 2 < 64) xl >>= 1;     // at least 64 channels per pixel row if C has them
+    while (xl > 8 && (256 / xl) * 2 <= g.chunks && (256 / xl) * ne * 2 < 128) xl >>= 1;    // whole 128-byte lines (64 bf16 channels) per pixel if C has them
     while (xl > 4 && 256 / xl < 1) xl >>= 1;
     // narrow maps: 30 useful columns of 32 cover W = 64 with a third of the lanes idle (3 x 32 for 64); 14 of 16 waste less there
     if (xl == 32 && g.chunks >= 16 && cdiv(W, 14) * 16 < cdiv(W, 30) * 32) xl = 16;
