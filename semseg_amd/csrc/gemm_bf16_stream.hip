@@ -1,5 +1,5 @@
 // Streaming NT GEMM for the thin projections of the token path: C[M, N] = epilogue(A[M, K] . B[N, K]^T) with K = 64 or 128 and
-// N <= 256 (MiT stage-1 fc1 / the data gradient of fc2: M = 1048576, N = 256, K = 64 -- 134 MB in, 537 MB out, 34 flop per byte).
+// N <= 256 per workgroup (MiT stage-1 fc1 / the data gradient of fc2: M = 1048576, N = 256, K = 64 -- 134 MB in, 537 MB out, 34 flop per byte).
 //
 // Such a launch is a copy with a matrix product in the middle, and the tile kernels run it as load -> barrier -> MFMA -> barrier ->
 // LDS image -> barrier -> store per workgroup, at the speed of the slowest phase of each tile.  Here there is no workgroup barrier
@@ -21,7 +21,7 @@ __device__ __forceinline__ int st_slot(int row, int chunk) {      // 16-byte slo
 // Plain epilogue (bias, row scale) through a wave-private [32 rows][HB * 32 columns] LDS strip: whole 128-byte lines leave per row
 // (nt_epilogue_wave writes 64-byte halves of a line from two different instructions).
 template <int NT, int HB>
-__device__ __forceinline__ void stream_epilogue(floatx16 (&acc)[1][NT], const FastGemm& p, char* wl, int64_t m0, int lane) {
+__device__ __forceinline__ void stream_epilogue(floatx16 (&acc)[1][NT], const FastGemm& p, char* wl, int64_t m0, int n0, int lane) {
     constexpr int PITCH = HB * 64 + 16, CPR = HB * 4, RPP = 64 / CPR;      // bytes per strip row; 16-byte chunks per row; rows per pass
     const int li = lane & 31, lh = lane >> 5;
     const int64_t m = m0 + li;
@@ -38,7 +38,7 @@ __device__ __forceinline__ void stream_epilogue(floatx16 (&acc)[1][NT], const Fa
             for (int g = 0; g < 4; ++g) {
                 const int nl = bl * 32 + 8 * g + 4 * lh;
                 floatx4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bv = *(const floatx4*)(p.bias + half * HB * 32 + nl);
+                if (p.bias) bv = *(const floatx4*)(p.bias + n0 + half * HB * 32 + nl);
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (bf16)((acc[0][b][4 * g + e] + bv[e]) * rs);
@@ -50,26 +50,28 @@ __device__ __forceinline__ void stream_epilogue(floatx16 (&acc)[1][NT], const Fa
         for (int ps = 0; ps < 32 / RPP; ++ps) {
             const int r = ps * RPP + rr;
             const bf16x8 v = *(const bf16x8*)(wl + r * PITCH + cc * 16);
-            if (m0 + r < p.M) *(bf16x8*)(C + (m0 + r) * p.ldc + half * HB * 32 + cc * 8) = v;
+            if (m0 + r < p.M) *(bf16x8*)(C + (m0 + r) * p.ldc + n0 + half * HB * 32 + cc * 8) = v;
         }
         asm volatile("" ::: "memory");
     }
 }
 
-template <int NT, int KT>                          // N = 32 * NT columns, K = 64 * KT
-__global__ __launch_bounds__(256, 2) void gemm_nt_stream_kernel(FastGemm p, int ntiles) {
+// N = 32 * NT columns per workgroup (blockIdx.y selects the column block), K = 64 * KT, WAVES waves per workgroup
+template <int NT, int KT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gemm_nt_stream_kernel(FastGemm p, int ntiles) {
     constexpr int N = 32 * NT, IMG = N * 64;       // elements of one k-tile image of B
     constexpr int HB = NT < 4 ? NT : 4, STRIP = 32 * (HB * 64 + 16);
     __shared__ __attribute__((aligned(16))) bf16 Bs[KT * IMG];
-    __shared__ __attribute__((aligned(16))) char epi[4 * STRIP];
+    __shared__ __attribute__((aligned(16))) char epi[WAVES * STRIP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    for (int c = tid; c < KT * N * 8; c += 256) {
+    const int n0 = blockIdx.y * N;
+    for (int c = tid; c < KT * N * 8; c += 64 * WAVES) {
         const int kt = c / (N * 8), rc = c - kt * (N * 8), row = rc >> 3, ch = rc & 7;
-        *(bf16x8*)(Bs + kt * IMG + st_slot(row, ch) * 8) = *(const bf16x8*)(p.B + (int64_t)row * p.ldb + kt * 64 + ch * 8);
+        *(bf16x8*)(Bs + kt * IMG + st_slot(row, ch) * 8) = *(const bf16x8*)(p.B + (int64_t)(n0 + row) * p.ldb + kt * 64 + ch * 8);
     }
     __syncthreads();
-    const int stride = gridDim.x * 4;
-    int t = blockIdx.x * 4 + wave;
+    const int stride = gridDim.x * WAVES;
+    int t = blockIdx.x * WAVES + wave;
     if (t >= ntiles) return;
     bf16x8 fn[KT * 4];
     auto aload = [&](int tile) {
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stream_kernel(FastGemm p, int 
                 acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa[ks], acc[0][b], 0, 0, 0);
             }
         }
-        stream_epilogue<NT, HB>(acc, p, epi + wave * STRIP, (int64_t)t * 32, lane);
+        stream_epilogue<NT, HB>(acc, p, epi + wave * STRIP, (int64_t)t * 32, n0, lane);
     }
 }
 
@@ -119,11 +121,15 @@ int cu_count() {
 // plain epilogues only (bias, row scale: no activation, residual, tile statistics, second product, patch addressing, second output)
 bool ss_stream_nt_ok(const FastGemm& p) {
     static int mode = -1;                                  // SS_GEMM_STREAM=0 switches the kernel off (A/B measurements)
-    if (mode < 0) { const char* e = getenv("SS_GEMM_STREAM"); mode = e && e[0] == '0' ? 0 : 1; }
+    if (mode < 0) { const char* e = getenv("SS_GEMM_STREAM"); mode = e ? atoi(e) : 1; }
     if (!mode || p.stat_ws || p.w2 || p.C2 || p.pm.side || p.res || p.act) return false;
     // measured inside the training step: M = 1048576, N = 256, K = 64: 156 us against 202 us on the 128-row tile kernel (4.3 TB/s of
     // in + out); N = 64: 58 against 66 us; K = 128 (N = 128, M = 262144) 38.6 against 36.6 us, so K = 128 stays on the tile kernels
-    if (p.K != 64 || !(p.N == 64 || p.N == 128 || p.N == 256)) return false;
+    // N = 512, K = 128 (the Lawin branch projections, M = 262144): two column blocks of 256 (blockIdx.y), 8 waves per workgroup
+    // around one 64 KB weight block
+    // (95.7 against 100.7 us on the persistent 256-tile kernel, same box)
+    const bool wide = p.K == 128 && p.N == 512;
+    if (!wide && (p.K != 64 || !(p.N == 64 || p.N == 128 || p.N == 256))) return false;
     return p.M >= 32 * 8 * 4 * (int64_t)cu_count();
 }
 
@@ -132,12 +138,12 @@ int ss_stream_nt_launch(FastGemm p, hipStream_t st) {
     // workgroups per CU by register use: 224-256 VGPRs at N = 256 (2), ~160 at N = 128 or K = 128 (3), 116 at N = K = 64 (4)
     const int per_cu = p.N == 256 ? (p.K == 64 ? 2 : 1) : (p.N == 64 && p.K == 64 ? 4 : 3);      // by registers; N = 256, K = 128 by LDS (100 KB)
     const dim3 grid((unsigned)(per_cu * cu_count())), block(256);
-#define SS_STREAM(NT, KT) hipLaunchKernelGGL((gemm_nt_stream_kernel<NT, KT>), grid, block, 0, st, p, ntiles)
-    if (p.K == 64) {
-        if (p.N == 64) SS_STREAM(2, 1); else if (p.N == 128) SS_STREAM(4, 1); else SS_STREAM(8, 1);
-    } else {
-        if (p.N == 64) SS_STREAM(2, 2); else if (p.N == 128) SS_STREAM(4, 2); else SS_STREAM(8, 2);
-    }
+#define SS_STREAM(NT, KT) hipLaunchKernelGGL((gemm_nt_stream_kernel<NT, KT, 4>), grid, block, 0, st, p, ntiles)
+    if (p.K == 128 && p.N == 512)
+        hipLaunchKernelGGL((gemm_nt_stream_kernel<8, 2, 8>), dim3((unsigned)cu_count(), 2), dim3(512), 0, st, p, ntiles);
+    else if (p.N == 64) SS_STREAM(2, 1);
+    else if (p.N == 128) SS_STREAM(4, 1);
+    else SS_STREAM(8, 1);
 #undef SS_STREAM
     SS_LAUNCH_CHECK();
     return 0;

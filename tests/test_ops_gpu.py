@@ -67,7 +67,7 @@ def test_gemm_nt(ops, dtype, M, N, K):
                                    (131072 + 77, 512, 256), (65536 + 300, 1280, 320), (131072 + 9, 512, 128),   # its persistent form (>= 4 tiles per CU)
                                    (65536 + 5, 256, 96), (131072, 128, 64), (70000, 256, 32 * 11), (33000, 512, 128),    # long-M shapes of the 128 tile kernel
                                    (262144 + 77, 256, 64), (262144 + 5, 64, 64), (262144 + 33, 128, 64), (262144 + 40, 128, 128),
-                                   (262144 + 1, 64, 128), (270000, 256, 128)])                         # the streaming kernel (K = 64 / 128, N <= 256, M >= 262144)
+                                   (262144 + 1, 64, 128), (270000, 256, 128), (262144 + 70, 512, 128)])                         # the streaming kernel (K = 64 / 128, N <= 256, M >= 262144)
 def test_gemm_nt_bf16_fast_path(ops, M, N, K):
     """shapes that take the 128 x {64,128} x 64 bf16 kernels: ragged M, K tails (K % 64 != 0), N tails, bias + GELU + DropPath row
     scale + residual in the epilogue, and writes into a channel slice of a wider buffer."""
