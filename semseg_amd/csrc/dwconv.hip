@@ -12,6 +12,11 @@
 #include "colreduce.h"
 
 #define DW_UNROLL 9                                   // rows per loop iteration: divides the strip height, a multiple of the window height 3
+// forward kernel: rows in flight per thread (the ring) and its loop unroll, a multiple of both the ring depth and the window height
+#ifndef DW_FWD_RING
+#define DW_FWD_RING 3                                 // 4 rows in flight (246 VGPRs, strips in multiples of 12) measured 7 % slower
+#endif
+#define DW_FWD_UNROLL (3 * DW_FWD_RING)
 
 template <typename T, int N> using vecn = T __attribute__((ext_vector_type(N)));
 
@@ -26,7 +31,7 @@ template <int NE> __device__ __forceinline__ void loadf(const float* p, float (&
 }
 
 struct DwGeom { int cpb, xl, groups, xtiles, ystrips, chunks, ty; };
-static inline DwGeom dw_geom(int B, int H, int W, int C, int ne) {
+static inline DwGeom dw_geom(int B, int H, int W, int C, int ne, int unr = DW_UNROLL) {
     DwGeom g; g.chunks = C / ne;
     const int cap = ne == 8 ? 16 : 64;                  // 128 channels = two 128-byte lines per pixel, 16 columns per workgroup (32 / 8 columns: 3 % slower)
     int cpb = 1; while (cpb < g.chunks && cpb < cap) cpb <<= 1;
@@ -34,11 +39,11 @@ static inline DwGeom dw_geom(int B, int H, int W, int C, int ne) {
     g.xtiles = (int)cdiv(W, g.xl);
     // rows per strip: a multiple of DW_UNROLL.  Taller strips amortise the fill of window + ring and the 2 halo rows (about 6 rows
     // of work per strip); rows past the image bottom are computed and dropped; and the launch wants >= 8 workgroups per CU.
-    int best = 2 * DW_UNROLL; int64_t best_cost = -1;
-    for (int ty = 2 * DW_UNROLL; ty <= 8 * DW_UNROLL; ty += DW_UNROLL) {
+    int best = 2 * unr; int64_t best_cost = -1;
+    for (int ty = 2 * unr; ty <= 8 * unr; ty += unr) {
         const int64_t strips = cdiv(H, ty), cost = strips * (ty + 6);
         const int64_t blocks = strips * g.xtiles * g.groups * B;
-        if (ty > 2 * DW_UNROLL && blocks < 2048) break;
+        if (ty > 2 * unr && blocks < 2048) break;
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = ty; }
     }
     g.ty = best; g.ystrips = (int)cdiv(H, g.ty);
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3_fwd_kernel(const T* __restrict
     const int yend = min(H, y0 + g.ty);
     const int ylast = min(H - 1, yend);                    // last row any output of the strip reads
     float win[3][3][NE];
-    V ring[3][3];
+    V ring[DW_FWD_RING][3];
     {
         V raw[3];
         unsigned k = y0 > 0 ? ~0u : 0u;
@@ -164,13 +169,13 @@ __global__ __launch_bounds__(256, 2) void dwconv3_fwd_kernel(const T* __restrict
         k = y0 + 1 < H ? ~0u : 0u;
         dw_issue_row<T, NE>(px + (y0 + 1 < H ? rs : 0), offL, offR, raw); dw_cvt_row<T, NE>(raw, mL & k, k, mR & k, win[2]);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) dw_issue_row<T, NE>(px + (min(y0 + 2 + j, ylast) - y0) * rs, offL, offR, ring[(2 + j) % 3]);
+        for (int j = 0; j < DW_FWD_RING; ++j) dw_issue_row<T, NE>(px + (min(y0 + 2 + j, ylast) - y0) * rs, offL, offR, ring[(2 + j) % DW_FWD_RING]);
     }
     // Branch-free steps (a row past the strip's end is computed from clamped loads and not stored), DW_UNROLL rows per loop
     // iteration: the compiler's wait counts are exact inside an iteration and conservative only across the back edge.
-    for (int yy = y0; yy < yend; yy += DW_UNROLL) {
+    for (int yy = y0; yy < yend; yy += DW_FWD_UNROLL) {
 #pragma unroll
-        for (int i = 0; i < DW_UNROLL; ++i) {               // window rows rotate through the three slots: no register moves
+        for (int i = 0; i < DW_FWD_UNROLL; ++i) {           // window rows rotate through the three slots: no register moves
             const int yc = yy + i;
             float u[NE];
             dw_taps<NE>(win[i % 3], win[(i + 1) % 3], win[(i + 2) % 3], wt, bv, u);
@@ -186,10 +191,10 @@ __global__ __launch_bounds__(256, 2) void dwconv3_fwd_kernel(const T* __restrict
             }
             if (yc < yend) *(V*)(py + i * rs) = o;
             const unsigned k = yc + 2 < H ? ~0u : 0u;
-            dw_cvt_row<T, NE>(ring[(i + 2) % 3], mL & k, k, mR & k, win[i % 3]);                   // row yc+2 enters the window
-            dw_issue_row<T, NE>(px + (min(yc + 5, ylast) - yy) * rs, offL, offR, ring[(i + 2) % 3]);  // row yc+5 starts travelling
+            dw_cvt_row<T, NE>(ring[(i + 2) % DW_FWD_RING], mL & k, k, mR & k, win[i % 3]);         // row yc+2 enters the window
+            dw_issue_row<T, NE>(px + (min(yc + 2 + DW_FWD_RING, ylast) - yy) * rs, offL, offR, ring[(i + 2) % DW_FWD_RING]);  // the next row starts travelling
         }
-        px += DW_UNROLL * rs; py += DW_UNROLL * rs;
+        px += DW_FWD_UNROLL * rs; py += DW_FWD_UNROLL * rs;
     }
 }
 
@@ -499,7 +504,7 @@ extern "C" int ss_dwconv3_fwd(int dtype, const void* x, const float* w9c, const 
                               int act, hipStream_t stream) {
     SS_CHECK(x && w9c && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "ss_dwconv3_fwd: bad arguments (C=%d)", C);
     SS_CHECK(aligned16(x) && aligned16(y) && aligned16(w9c) && (!bias || aligned16(bias)), "ss_dwconv3_fwd: pointers must be 16-byte aligned");
-    DwGeom g = dw_geom(B, H, W, C, dtype == SS_BF16 ? 8 : 4);
+    DwGeom g = dw_geom(B, H, W, C, dtype == SS_BF16 ? 8 : 4, DW_FWD_UNROLL);
     SS_CHECK((int64_t)g.xtiles * g.ystrips < 2147483647LL && B < 65536 && g.groups < 65536, "ss_dwconv3_fwd: grid too large");
     dim3 grid((unsigned)(g.xtiles * g.ystrips), g.groups, B);
     SS_CHECK(act == 0 || act == 1, "ss_dwconv3_fwd: act must be 0 (none) or 1 (GELU)");
