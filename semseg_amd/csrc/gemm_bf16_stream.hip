@@ -6,9 +6,9 @@
 // after the weights have been staged: the whole B operand (N x K, <= 64 KB) sits in LDS for the lifetime of the workgroup, and every
 // WAVE is a pipeline of its own over 32-row tiles of A -- the 16-byte fragment loads of tile t+1 are in flight (they go straight
 // from global memory into the MFMA operand registers: a lane is a row, its 16 bytes are one k-chunk, four loads cover the row's
-// 128-byte line) while tile t is multiplied and its 32 x N result leaves through the wave's own 2 KiB LDS strip
-// (bias and row scale only: other epilogues stay on the tile kernels).  Stores are asynchronous, so a wave's
-// stores of tile t overlap its MFMAs of tile t+1 and every other wave's loads.
+// 128-byte line) while tile t is multiplied and its 32 x N result leaves through the wave's own LDS strip (32 rows x 128 columns
+// at a time; bias and row scale only: other epilogues stay on the tile kernels).  Stores are asynchronous, so a wave's stores of
+// tile t overlap its MFMAs of tile t+1 and every other wave's loads.
 #include "gemm_fast.h"
 
 namespace {
@@ -124,10 +124,9 @@ bool ss_stream_nt_ok(const FastGemm& p) {
     if (mode < 0) { const char* e = getenv("SS_GEMM_STREAM"); mode = e ? atoi(e) : 1; }
     if (!mode || p.stat_ws || p.w2 || p.C2 || p.pm.side || p.res || p.act) return false;
     // measured inside the training step: M = 1048576, N = 256, K = 64: 156 us against 202 us on the 128-row tile kernel (4.3 TB/s of
-    // in + out); N = 64: 58 against 66 us; K = 128 (N = 128, M = 262144) 38.6 against 36.6 us, so K = 128 stays on the tile kernels
-    // N = 512, K = 128 (the Lawin branch projections, M = 262144): two column blocks of 256 (blockIdx.y), 8 waves per workgroup
-    // around one 64 KB weight block
-    // (95.7 against 100.7 us on the persistent 256-tile kernel, same box)
+    // in + out); N = 64: 58 against 66 us; K = 128 at N = 128 (M = 262144): 38.6 against 36.6 us, so that shape stays on the tile kernels.
+    // N = 512, K = 128 (MiT stage-2 fc1 and the data gradient of fc2, M = 262144): two column blocks of 256 (blockIdx.y), 8 waves per
+    // workgroup around one 64 KB weight block: 95.7 against 100.7 us on the persistent 256-tile kernel (same box)
     const bool wide = p.K == 128 && p.N == 512;
     if (!wide && (p.K != 64 || !(p.N == 64 || p.N == 128 || p.N == 256))) return false;
     return p.M >= 32 * 8 * 4 * (int64_t)cu_count();
@@ -135,8 +134,8 @@ bool ss_stream_nt_ok(const FastGemm& p) {
 
 int ss_stream_nt_launch(FastGemm p, hipStream_t st) {
     const int ntiles = (int)cdiv(p.M, 32);
-    // workgroups per CU by register use: 224-256 VGPRs at N = 256 (2), ~160 at N = 128 or K = 128 (3), 116 at N = K = 64 (4)
-    const int per_cu = p.N == 256 ? (p.K == 64 ? 2 : 1) : (p.N == 64 && p.K == 64 ? 4 : 3);      // by registers; N = 256, K = 128 by LDS (100 KB)
+    // workgroups per CU by register use: 240 VGPRs at N = 256 (2), ~164 at N = 128 (3), 110 at N = 64 (4)
+    const int per_cu = p.N == 256 ? 2 : (p.N == 64 ? 4 : 3);
     const dim3 grid((unsigned)(per_cu * cu_count())), block(256);
 #define SS_STREAM(NT, KT) hipLaunchKernelGGL((gemm_nt_stream_kernel<NT, KT, 4>), grid, block, 0, st, p, ntiles)
     if (p.K == 128 && p.N == 512)
