@@ -306,6 +306,8 @@ extern "C" int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, co
     SS_CHECK(!res || ldr >= N, "ss_gemm_nt: bad ldr");
     SS_CHECK(!rowscale || rows_per_scale > 0, "ss_gemm_nt: rows_per_scale must be > 0");
     SS_CHECK(cdiv(M, 128) * cdiv(N, 64) < 2147483647LL, "ss_gemm_nt: too many tiles");
+    if (dtype == SS_BF16 && !res && !rowscale && act == 0 && ss_tinym_nt_ok(M, N, K, A, lda, B, ldb))
+        return ss_tinym_nt_launch((const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, out_f32, M, N, K, bias, stream);
     if (dtype == SS_BF16 && !out_f32) {
         FastGemm f{};
         f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = C; f.M = M; f.N = (int)N; f.K = K; f.lda = lda; f.ldb = ldb; f.ldc = ldc;

@@ -80,6 +80,9 @@ int ss_patch_nt_launch(FastGemm p, hipStream_t st);
 int ss_patch_tn_launch(FastGemm p, int nsplit, hipStream_t st);
 bool ss_skinny_nt_ok(const FastGemm& p);
 int ss_skinny_nt_launch(const FastGemm& p, hipStream_t st);
+bool ss_tinym_nt_ok(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb);      // M <= 16 rows: a wave per output column
+int ss_tinym_nt_launch(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int64_t M, int64_t N,
+                       int64_t K, const float* bias, hipStream_t st);
 bool ss_skinny_tn_ok(const void* B, int64_t ldb, int64_t M, int64_t N);
 int ss_skinny_tn_launch(const FastGemm& p, int nsplit, hipStream_t st);
 bool ss_stream_nt_ok(const FastGemm& p);                 // gemm_bf16_stream.hip: K = 64 / 128, N <= 256, every wave a pipeline of its own

@@ -123,3 +123,48 @@ int ss_skinny_tn_launch(const FastGemm& p, int nsplit, hipStream_t st) {
     SS_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------ NT with M <= 16 rows (the per-image vectors of LawinHead's image-pool
+// branch: 16 x 512 x 512): a wave per output column n keeps that weight row in registers (a lane holds 16-byte k-chunks), multiplies
+// it with the M rows of A (16 KB, served by L1 / L2) and reduces across its lanes in a fixed order.  The 128-row tile kernel spends
+// 20 us on such a launch (one row tile, 8 k-iterations of latency), the generic fp32-output kernel 40 us.
+template <typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_tinym_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb,
+        TO* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const bf16x8 w = *(const bf16x8*)(B + (int64_t)n * ldb + k);
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if (m < M) {
+                const bf16x8 a = *(const bf16x8*)(A + (int64_t)m * lda + k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[m] = fmaf((float)a[e], (float)w[e], acc[m]);
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        if (m < M) {
+            float v = acc[m];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) C[(int64_t)m * ldc + n] = (TO)(v + (bias ? bias[n] : 0.f));
+        }
+}
+
+bool ss_tinym_nt_ok(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb) {
+    return M <= 16 && N >= 64 && K >= 64 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B);
+}
+
+int ss_tinym_nt_launch(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int64_t M, int64_t N,
+                       int64_t K, const float* bias, hipStream_t st) {
+    const dim3 grid((unsigned)cdiv(N, 4)), block(256);
+    if (out_f32) hipLaunchKernelGGL(gemm_nt_tinym_kernel<float>, grid, block, 0, st, A, lda, B, ldb, (float*)C, ldc, (int)M, (int)N, (int)K, bias);
+    else hipLaunchKernelGGL(gemm_nt_tinym_kernel<bf16>, grid, block, 0, st, A, lda, B, ldb, (bf16*)C, ldc, (int)M, (int)N, (int)K, bias);
+    SS_LAUNCH_CHECK();
+    return 0;
+}

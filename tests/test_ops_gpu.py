@@ -142,6 +142,21 @@ def test_gemm_tn_droppath_keep(ops, R, M, N, rpk):
     assert not ops.gemm_tn_keep_ok(ad, bd, 96) and not ops.gemm_tn_keep_ok(ad.float(), bd.float(), rpk)
 
 
+@pytest.mark.parametrize('M,N,K', [(16, 512, 512), (2, 512, 512), (1, 64, 64), (7, 200, 1032), (16, 6, 512)])
+def test_gemm_nt_few_rows(ops, M, N, K):
+    """M <= 16 rows in bf16 (the per-image vectors of the image-pool branch): the wave-per-column kernel, both output dtypes"""
+    dtype = torch.bfloat16
+    a, b, bias = rnd(M, K), rnd(N, K, seed=1) / math.sqrt(K), rnd(N, seed=2)
+    ref = q(a, dtype) @ q(b, dtype).t() + bias
+    out = ops.gemm_nt(dev(a, dtype), dev(b, dtype), bias=dev(bias))
+    assert out.dtype == dtype and rel(out, ref) < 1e-2
+    out32 = ops.gemm_nt(dev(a, dtype), dev(b, dtype), bias=dev(bias), out_f32=True)
+    assert out32.dtype == torch.float32 and rel(out32, ref) < 1e-5
+    wide = torch.full((M, N + 16), 7.0, dtype=torch.float32, device='cuda')
+    ops.gemm_nt(dev(a, dtype), dev(b, dtype), out=wide[:, 8:8 + N], out_f32=True)
+    assert rel(wide[:, 8:8 + N], ref - bias) < 1e-5 and float((wide[:, :8] - 7).abs().max()) == 0 and float((wide[:, 8 + N:] - 7).abs().max()) == 0
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_gemm_nt_strided(ops, dtype):
     big_a, b = rnd(200, 96), rnd(40, 32, seed=1)
