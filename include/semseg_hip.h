@@ -121,7 +121,9 @@ int ss_bn_bwd_coef(int dtype, const void* dy, int64_t ldd, const void* z, int64_
  * tensor is never written.  y, dy and dz are [B*ho*wo, C]; dz is the gradient of the resized map (ss_bilinear_bwd takes it to x).
  * bvec (NULL = none; x2 resize only): [B, C] fp32 added to the resized value of image b -- the image-pool branch of the concat in
  * front of `cat` (modules/lawin.py:205-210) is constant over an image, so its share of the conv is one vector per image that
- * commutes with the resize instead of E of the conv's 5E input columns; its gradient is the per-image column sum of dx. */
+ * commutes with the resize instead of E of the conv's 5E input columns; its gradient is the per-image column sum of dx.
+ * workspace (ss_bn_stats_up) >= 1024*2*C floats, (ss_bn_bwd_up, ss_bn_bwd_up2_dx) >= (1024*2*C + 2*C) floats: enough for every
+ * geometry (the partial rows of the first pass never exceed 1024); the calls check the exact need. */
 int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, const float* bvec, int B, int hi, int wi, int ho, int wo, int C, float eps, float momentum,
                    float* stats, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* workspace,
                    int64_t ws_bytes, hipStream_t stream);
@@ -356,6 +358,9 @@ int ss_softmax2d_bwd(int dtype, const void* y, int64_t yn, int64_t yc, int64_t y
  * first maximum wins ties. */
 int ss_confusion_update(int dtype, const void* logits, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* labels,
                         int64_t* cm, int B, int C, int H, int W, hipStream_t stream);
+/* the same for predictions that already are class indices (helper/metrics.py:90-95: torchmetrics' ConfusionMatrix takes scores or
+ * int labels): pred, labels int64 [n]; pairs with either value outside [0, C) are not counted. */
+int ss_confusion_indices(const int64_t* pred, const int64_t* labels, int64_t* cm, int64_t n, int C, hipStream_t stream);
 
 /* ---- Next rows of SURVEY.md 8(f): the steps right after the forward in predict.py and scripts/evaluate.py.
  * ss_class_map_u8: PredictionWriter.write_on_batch_end (helper/callbacks.py:52-54), prediction.softmax(1).argmax(1): softmax is
@@ -477,7 +482,7 @@ int ss_simam_apply(int dtype, const void* x, int64_t ldx, const float* moments, 
                    int64_t rows_per_image, int C, int images, hipStream_t stream);
 /* SimAM and the grouped 1x1 conv that consumes it in one kernel (modules/heads.py:27-39 + :200-222): out[p][n] (fp32) =
  * sum_c w[n][c] * att[p][c], att = ss_simam_apply's output rounded to the compute dtype -- which is then never written.
- * ss_simam_gemm_ok: 1 for bf16, C a power of two in 64..2048, N <= 32 and a multiple of 4; else callers run ss_simam_apply + ss_gemm_nt. */
+ * ss_simam_gemm_ok: 1 for bf16, C a power of two in 64..1024 (the LDS tile), N <= 32 and a multiple of 4; else callers run ss_simam_apply + ss_gemm_nt. */
 int ss_simam_gemm_ok(int dtype, int C, int N);
 int ss_simam_gemm(int dtype, const void* x, int64_t ldx, const float* moments, const float* k, const void* w, int64_t ldw, float* out,
                   int64_t ldo, int64_t rows_per_image, int C, int images, int N, hipStream_t stream);

@@ -239,7 +239,9 @@ extern "C" int ss_ir_block_ok(int dtype, int Cin, int hidp, int Cout, int k, int
     if (dtype != SS_BF16 || (k != 3 && k != 5) || (s != 1 && s != 2)) return 0;
     if (Cin <= 0 || Cin % 8 || Cin > 64 || Cout <= 0 || Cout % 8 || hidp <= 0 || hidp % 32) return 0;
     const int cinp = (Cin + 15) / 16 * 16, coutp = (Cout + 31) / 32 * 32;
-    return ir_lds_bytes(k, s, ir_tile_rows(k, s, cinp, hidp, coutp), cinp, hidp, coutp) <= 80 * 1024;      // two workgroups per CU
+    const int th = ir_tile_rows(k, s, cinp, hidp, coutp);
+    if ((int64_t)th * hidp > 1024) return 0;                                                             // the depthwise item table of ss_ir_block_fwd
+    return ir_lds_bytes(k, s, th, cinp, hidp, coutp) <= 80 * 1024;                                       // two workgroups per CU
 }
 
 // x [B, H, W, Cin] -> y [B, Ho, Wo, Cout] (channels-last bf16).  w_in [hidp][cinp] (cinp = Cin rounded up to 16), b_in [hidp],

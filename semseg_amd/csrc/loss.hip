@@ -370,6 +370,27 @@ __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ lo
     }
 }
 
+// the same accumulator for predictions that already are class indices (torchmetrics takes both forms, helper/metrics.py:90-95):
+// pixels whose target or prediction lies outside [0, C) are not counted
+__global__ __launch_bounds__(256) void confusion_indices_kernel(const long long* __restrict__ pred, const long long* __restrict__ labels,
+                                                                unsigned long long* __restrict__ cm, int64_t npix, int C, int copies) {
+    extern __shared__ unsigned bins[];
+    const int cc = C * C;
+    for (int i = threadIdx.x; i < cc * copies; i += blockDim.x) bins[i] = 0;
+    __syncthreads();
+    unsigned* mine = bins + (threadIdx.x % copies) * cc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long lab = labels[i], arg = pred[i];
+        if (lab >= 0 && lab < C && arg >= 0 && arg < C) atomicAdd(&mine[(int)lab * C + (int)arg], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cc; i += blockDim.x) {
+        unsigned long long t = 0;
+        for (int k = 0; k < copies; ++k) t += bins[k * cc + i];
+        if (t) atomicAdd(&cm[i], t);
+    }
+}
+
 // ------------------------------------------------------------------ label histogram: hist[v] += #(labels == v), v in [0, nbins)
 // helper/weights.py:18-27 builds a [pixels x classes] boolean matrix to count the labels; one pass over the int64 labels with
 // per-workgroup LDS bins (lane l counts in copy l % copies) and one 64-bit global add per non-empty bin.  Exact.
@@ -654,6 +675,16 @@ extern "C" int ss_confusion_update(int dtype, const void* logits, int64_t sn, in
     const int copies = cm_copies(C);
     SS_DISPATCH(dtype, hipLaunchKernelGGL((confusion_kernel<T>), dim3(nblk(npix, 2048)), dim3(256), (size_t)C * C * copies * sizeof(unsigned), stream,
                                           (const T*)logits, s, (const long long*)labels, (unsigned long long*)cm, npix, H, W, C, copies));
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// pred, labels: int64 [n] class indices; cm as above
+extern "C" int ss_confusion_indices(const int64_t* pred, const int64_t* labels, int64_t* cm, int64_t n, int C, hipStream_t stream) {
+    SS_CHECK(pred && labels && cm && n > 0 && C > 0 && C <= 100, "ss_confusion_indices: bad arguments (1 <= C <= 100)");
+    const int copies = cm_copies(C);
+    hipLaunchKernelGGL(confusion_indices_kernel, dim3(nblk(n, 2048)), dim3(256), (size_t)C * C * copies * sizeof(unsigned), stream,
+                       (const long long*)pred, (const long long*)labels, (unsigned long long*)cm, n, C, copies);
     SS_LAUNCH_CHECK();
     return 0;
 }

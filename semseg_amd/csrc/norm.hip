@@ -366,6 +366,14 @@ namespace w4 {
 #undef UN
 static inline bool up2_ok(int hi, int wi, int ho, int wo) { return ho == 2 * hi && wo == 2 * wi; }
 
+// partial rows the first pass of a resize-BatchNorm kernel writes: the x2 walker's block count can exceed the column geometry's on
+// thin maps (C = 64, 64 x 2 -> 128 x 4: 11 against 4), so the workspace check and the offset of `coef` use the larger of the two
+static inline int up_partial_rows(int nb_cols, int B, int hi, int wi, int ho, int wo, int C) {
+    if (!up2_ok(hi, wi, ho, wo)) return nb_cols;
+    const int nb2 = w4::up2_blocks(w4::up2_geom(B, hi, wi, C), B);
+    return nb2 > nb_cols ? nb2 : nb_cols;
+}
+
 #define SS_UP_CHECK(name) \
     SS_CHECK(B > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && (int64_t)B * ho * wo < (1LL << 31) && (int64_t)B * hi * wi * ldx < (1LL << 40), \
              name ": bad resize geometry")
@@ -377,7 +385,7 @@ extern "C" int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, const float
     SS_CHECK(!bvec || up2_ok(hi, wi, ho, wo), "ss_bn_stats_up: a per-image constant is only taken by the x2 resize");
     const int64_t rows = (int64_t)B * ho * wo;
     ColGeom g = col_geom(rows, C);
-    SS_CHECK(ws_bytes >= (int64_t)g.nb * 2 * C * 4, "ss_bn_stats_up: workspace too small");
+    SS_CHECK(ws_bytes >= (int64_t)up_partial_rows(g.nb, B, hi, wi, ho, wo, C) * 2 * C * 4, "ss_bn_stats_up: workspace too small");
     int nb = g.nb;
     if (up2_ok(hi, wi, ho, wo)) {
         using namespace w4;
@@ -713,8 +721,9 @@ extern "C" int ss_bn_bwd_up(int dtype, const void* dy, int64_t ldd, const void* 
     SS_CHECK(!bvec || up2_ok(hi, wi, ho, wo), "ss_bn_bwd_up: a per-image constant is only taken by the x2 resize");
     const int64_t rows = (int64_t)B * ho * wo;
     ColGeom g = col_geom(rows, C);
-    SS_CHECK(ws_bytes >= ((int64_t)g.nb * 2 * C + 2 * C) * 4, "ss_bn_bwd_up: workspace too small");
-    float* coef = workspace + (int64_t)g.nb * 2 * C;
+    const int nbw = up_partial_rows(g.nb, B, hi, wi, ho, wo, C);
+    SS_CHECK(ws_bytes >= ((int64_t)nbw * 2 * C + 2 * C) * 4, "ss_bn_bwd_up: workspace too small");
+    float* coef = workspace + (int64_t)nbw * 2 * C;
     BnWalk w{g.cpb, g.rpb};
     const int blocks2 = bn_walk_blocks(rows, g.rpb);
     const UpGeom up = up_geom(hi, wi, ho, wo);
@@ -765,8 +774,9 @@ extern "C" int ss_bn_bwd_up2_dx(int dtype, const void* dy, int64_t ldd, const vo
     SS_UP_CHECK("ss_bn_bwd_up2_dx");
     const int64_t rows = (int64_t)B * ho * wo;
     ColGeom g = col_geom(rows, C);
-    SS_CHECK(ws_bytes >= ((int64_t)g.nb * 2 * C + 2 * C) * 4, "ss_bn_bwd_up2_dx: workspace too small");
-    float* coef = workspace + (int64_t)g.nb * 2 * C;
+    const int nbw = up_partial_rows(g.nb, B, hi, wi, ho, wo, C);
+    SS_CHECK(ws_bytes >= ((int64_t)nbw * 2 * C + 2 * C) * 4, "ss_bn_bwd_up2_dx: workspace too small");
+    float* coef = workspace + (int64_t)nbw * 2 * C;
     using namespace w4;
     const Up2Geom u = up2_geom(B, hi, wi, C);
     const int nb = up2_blocks(u, B);

@@ -169,13 +169,14 @@ __global__ __launch_bounds__(256) void simam_gemm_kernel(const bf16* __restrict_
 }
 
 extern "C" int ss_simam_gemm_ok(int dtype, int C, int N) {
-    return dtype == SS_BF16 && C >= 64 && C <= 2048 && (C & (C - 1)) == 0 && N > 0 && N <= 32 && N % 4 == 0;
+    // the tile needs 64 * (2C + 16) bytes of LDS: 129 KiB at C = 1024, more than the CU's 160 KiB at C = 2048
+    return dtype == SS_BF16 && C >= 64 && C <= 1024 && (C & (C - 1)) == 0 && N > 0 && N <= 32 && N % 4 == 0;
 }
 
 extern "C" int ss_simam_gemm(int dtype, const void* x, int64_t ldx, const float* moments, const float* k, const void* w, int64_t ldw, float* out,
                              int64_t ldo, int64_t rows_per_image, int C, int images, int N, hipStream_t stream) {
     SS_CHECK(x && moments && k && w && out && rows_per_image > 1 && images > 0 && ss_simam_gemm_ok(dtype, C, N),
-             "ss_simam_gemm: needs bf16, C a power of two in 64..2048, N <= 32 and a multiple of 4 (C=%d N=%d)", C, N);
+             "ss_simam_gemm: needs bf16, C a power of two in 64..1024, N <= 32 and a multiple of 4 (C=%d N=%d)", C, N);
     SS_CHECK(ldx >= C && ldw >= C && ldo >= N && ldx % 8 == 0 && ldw % 8 == 0 && ldo % 4 == 0 && aligned16(x) && aligned16(w) && aligned16(out) && aligned16(moments),
              "ss_simam_gemm: operands must be 16-byte aligned");
     const int64_t tpi = cdiv(rows_per_image, 64);

@@ -83,8 +83,11 @@ class GradReducer:
     second ``backward()`` before ``wait()``, i.e. gradient accumulation -- raises (torch DDP raises there too); accumulate
     with ``overlap=False``, which reduces everything inside ``wait()``."""
 
-    def __init__(self, flat: FlatParams, bucket_bytes=25 << 20, overlap=True):
+    def __init__(self, flat: FlatParams, bucket_bytes=25 << 20, overlap=True, force_comm=False):
         self.flat, self.world = flat, _world()
+        # force_comm: run the hooks, the side stream and the collectives even in a world of one (a one-rank all-reduce is the
+        # identity), so the real backend's path can be exercised on a single GPU
+        self.active = self.world > 1 or (force_comm and dist.is_available() and dist.is_initialized())
         self.buckets = []                                      # (start, end, [param indices])
         start, members = 0, []
         for i, (p, o) in enumerate(zip(flat.params, flat.offsets)):
@@ -97,13 +100,13 @@ class GradReducer:
         for b, (_, _, mem) in enumerate(self.buckets):
             for i in mem:
                 self.bucket_of[i] = b
-        self.overlap = overlap and self.world > 1
+        self.overlap = overlap and self.active
         self.stream = torch.cuda.Stream() if (self.overlap and flat.data.is_cuda) else None
         self.comm_events = []                                  # (start, end) event pairs of the side stream, when timing is on
         self.time_comm = False
         self._rearm()
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for i, p in enumerate(flat.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_autograd_hook(i)))   # gradients through autograd
                 p._ss_grad_ready = self._make_delivery_hook(i)                                           # ... through runtime.deliver_grads
@@ -180,7 +183,7 @@ class GradReducer:
 
     def wait(self):
         """Launch whatever has not been launched (unused parameters, overlap off), join, re-arm.  -> grad_scale."""
-        if self.world > 1:
+        if self.active:
             for b in range(len(self.buckets)):
                 self._launch(b)
             for w in self.works:
@@ -278,7 +281,8 @@ class AdaBound:
             raise ValueError('AdaBound.load_state_dict: amsbound=True is not built (train.py:57 uses False)')
         self.lr, self.betas = float(group['lr']), tuple(group['betas'])
         self.final_lr, self.gamma, self.eps, self.wd = group['final_lr'], group['gamma'], group['eps'], group['weight_decay']
-        self.base_lr = float(sd.get('base_lrs', [self.lr])[0])
+        if 'base_lrs' in sd:                                   # torch_optimizer keeps base_lrs as a constructor attribute, not in state_dict:
+            self.base_lr = float(sd['base_lrs'][0])            # a torch / Lightning checkpoint leaves the constructor's lr in place
         steps = set()
         with torch.no_grad():
             for idx, p, o in self._slots():

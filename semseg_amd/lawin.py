@@ -16,7 +16,7 @@ import torch
 from torch import nn, Tensor
 
 from . import ops, weightprep
-from .runtime import compute_dtype_for, as_tokens_nhwc, deliver_grads, expect_grads
+from .runtime import compute_dtype_for, as_tokens_nhwc, deliver_grads, expect_grads, GradAwareFunction
 from .segformer import w_fwd, w_bwd, _sub
 from .shapes import LAWIN_BRANCHES
 
@@ -294,7 +294,7 @@ def _const(device, value):
     return t
 
 
-class LawinHeadFn(torch.autograd.Function):
+class LawinHeadFn(GradAwareFunction):
     @staticmethod
     def forward(ctx, module, drop_mask, names, x1, x2, x3, x4, *params):
         P = dict(zip(names, params))
@@ -319,7 +319,7 @@ class LawinHeadFn(torch.autograd.Function):
         return (None, None, None, *dfe, *grads)
 
 
-class _LawinFeatsFn(torch.autograd.Function):
+class _LawinFeatsFn(GradAwareFunction):
     @staticmethod
     def forward(ctx, module, names, x, *params):
         P, Bf = dict(zip(names, params)), dict(module.named_buffers())
@@ -408,7 +408,7 @@ class PatchEmbed(nn.Module):
         return _PatchPoolFn.apply(x, self.patch_size)
 
 
-class _LawinAttnFn(torch.autograd.Function):
+class _LawinAttnFn(GradAwareFunction):
     @staticmethod
     def forward(ctx, module, names, query, context, *params):
         P, Bf = dict(zip(names, params)), dict(module.named_buffers())

@@ -72,8 +72,10 @@ class SegmentationMetrics(nn.Module):
     def update(self, preds: torch.Tensor, target: torch.Tensor):
         if preds.dim() == 4:
             ops.confusion_update(preds.detach(), target.contiguous(), self.confmat)
-        else:                                   # already class indices [B, H, W]
-            raise NotImplementedError('SegmentationMetrics.update expects [B, C, H, W] scores')
+        elif preds.shape == target.shape and not preds.is_floating_point():    # already class indices [B, H, W]
+            ops.confusion_indices(preds.to(torch.int64).contiguous(), target.to(torch.int64).contiguous(), self.confmat)
+        else:
+            raise ValueError('SegmentationMetrics.update expects [B, C, H, W] scores or integer class indices shaped like target')
 
     def reset(self):
         self.confmat.zero_()

@@ -1000,6 +1000,19 @@ def confusion_update(logits, labels, cm):
     return cm
 
 
+def confusion_indices(pred, labels, cm):
+    """cm int64 [C, C] += counts of (target, pred) for int64 class-index predictions of the labels' shape."""
+    _dev(pred)
+    if pred.dtype != torch.int64 or labels.dtype != torch.int64 or pred.shape != labels.shape or labels.device != pred.device \
+            or not pred.is_contiguous() or not labels.is_contiguous():
+        raise ValueError('confusion_indices: pred and labels must be contiguous int64 tensors of one shape on one device')
+    if cm.dtype != torch.int64 or cm.dim() != 2 or cm.shape[0] != cm.shape[1] or not cm.is_contiguous():
+        raise ValueError('confusion_indices: cm must be contiguous int64 [C, C]')
+    if pred.numel():
+        check(lib().ss_confusion_indices(_p(pred), _p(labels), _p(cm), pred.numel(), cm.shape[0], _stream()))
+    return cm
+
+
 def _like_channels_last(x):
     B, C, H, W = x.shape
     return torch.empty((B, H, W, C), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)

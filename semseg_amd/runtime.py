@@ -1,4 +1,5 @@
 """Host-side runtime policy: compute dtype selection, layout adoption, DropPath multipliers."""
+import threading
 import warnings
 import torch
 
@@ -47,10 +48,31 @@ def drop_path_keep(b, drop_prob, dtype, device):
     return ops.droppath_keep(torch.rand((b, 1, 1), dtype=dtype, device=device), kp)
 
 
+_tls = threading.local()
+
+
+class GradAwareFunction(torch.autograd.Function):
+    """autograd.Function whose forward can tell whether a graph is being recorded.  Inside ``Function.forward`` grad mode is always
+    off and ``ctx.needs_input_grad`` is True for parameters under ``torch.no_grad()`` too, so ``apply`` notes the caller's grad mode
+    for ``expect_grads``: a validation forward must not announce gradients that no backward will deliver."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        prev = getattr(_tls, 'recording', None)
+        _tls.recording = torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            _tls.recording = prev
+
+
 def expect_grads(ctx, params, first):
     """Forward-side twin of ``deliver_grads``: tells whoever tracks gradient arrival (engine.GradReducer, through the parameter's
     ``_ss_grad_expect`` callback) that this graph node will deliver one gradient to each of its parameters, ``params`` being the
-    inputs ``first``, ``first + 1``, ... of the autograd Function whose forward is running."""
+    inputs ``first``, ``first + 1``, ... of the autograd Function whose forward is running.  Nothing is announced when the caller
+    runs under ``torch.no_grad()`` (``GradAwareFunction.apply``)."""
+    if getattr(_tls, 'recording', None) is False:
+        return
     for i, p in enumerate(params):
         cb = getattr(p, '_ss_grad_expect', None)
         if cb is not None and ctx.needs_input_grad[first + i]:

@@ -10,7 +10,7 @@ import torch
 from torch import nn, Tensor
 
 from . import ops, weightprep
-from .runtime import compute_dtype_for, as_tokens_nhwc, drop_path_keep, deliver_grads, expect_grads
+from .runtime import compute_dtype_for, as_tokens_nhwc, drop_path_keep, deliver_grads, expect_grads, GradAwareFunction
 from .shapes import MIT_VARIANTS, MIT_HEADS, MIT_SR, MIT_PATCH
 
 
@@ -151,7 +151,7 @@ def _names(module_or_names):
     return [n for n, _ in module_or_names.named_parameters()] if isinstance(module_or_names, nn.Module) else module_or_names
 
 
-class _ParamFn(torch.autograd.Function):
+class _ParamFn(GradAwareFunction):
     """Base: forward(ctx, x, meta, names, *params); subclasses implement fwd(P, x, meta) -> (out, S) and
     bwd(P, S, dout, meta) -> (dx, {name: grad})."""
 
@@ -275,7 +275,7 @@ class PatchEmbedFn(_ParamFn):
         return dx, G
 
 
-class StageNormFn(torch.autograd.Function):
+class StageNormFn(GradAwareFunction):
     """A stage's final LayerNorm (modules/segformer.py:180-198).  Its output has two consumers, the head and the next stage's patch
     embedding, so it is handed out twice (second output = a view of the first): backward then receives the two gradients separately and
     ``ss_layernorm_bwd`` sums them while it reads them, instead of autograd adding two full feature maps first."""

@@ -121,3 +121,33 @@ def _layout(net, align=64):
         offs.append((n, p.numel()))
         n += (p.numel() + align - 1) // align * align
     return offs
+
+
+def test_no_grad_forward_announces_no_gradients():
+    """runtime.expect_grads must stay silent for a forward under torch.no_grad(): ctx.needs_input_grad is True for parameters there too,
+    and a validation pass between two training steps would otherwise leave GradReducer waiting for gradients that never come (the
+    buckets would only travel inside wait())."""
+    sys.path.insert(0, ROOT)
+    from semseg_amd.runtime import GradAwareFunction, expect_grads
+
+    class Fn(GradAwareFunction):
+        @staticmethod
+        def forward(ctx, x, w):
+            expect_grads(ctx, (w,), 1)
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            return g, g
+
+    w = torch.nn.Parameter(torch.ones(3))
+    calls = []
+    w._ss_grad_expect = lambda p: calls.append(1)
+    x = torch.ones(3)
+    Fn.apply(x, w)
+    assert len(calls) == 1
+    with torch.no_grad():
+        Fn.apply(x, w)
+    assert len(calls) == 1
+    Fn.apply(x, w)
+    assert len(calls) == 2

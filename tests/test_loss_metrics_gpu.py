@@ -137,6 +137,24 @@ def test_confusion_matrix_bit_exact_and_scores():
     assert rep['confusion_matrix'].shape == (6, 6) and rep['class_report'].shape == (5, 5)
 
 
+def test_confusion_matrix_from_class_indices_equals_scores_path():
+    """helper/metrics.py:90-95: torchmetrics' ConfusionMatrix takes class-index predictions as well as scores; update() with
+    argmax(preds, 1) must add exactly what update() with the scores adds (bit-exact counts), out-of-range pairs dropped."""
+    from oracle import metrics as om
+    from semseg_amd.metrics import SegmentationMetrics
+    logits = det_input('mi.logits', (3, 6, 40, 56), -3, 3)
+    lab = det_labels('mi.lab', (3, 40, 56), 6, cell=4)
+    lab[0, :3] = 255                                   # a target outside 0..5 is not counted by either path
+    ref = om.confusion_matrix(logits, lab.clamp(max=5), 6) - om.confusion_matrix(logits[:1, :, :3], lab[:1, :3].clamp(max=5), 6)
+    m = SegmentationMetrics(6).cuda()
+    m.update(preds=logits.argmax(1).cuda(), target=lab.cuda())
+    assert torch.equal(m.confmat.cpu(), ref)
+    m.update(preds=logits.argmax(1).to(torch.uint8).cuda(), target=lab.cuda())      # an integer class map of another width
+    assert torch.equal(m.confmat.cpu(), 2 * ref)
+    with pytest.raises(ValueError):
+        m.update(preds=logits[:, 0].cuda(), target=lab.cuda())                      # float [B, H, W] is neither scores nor indices
+
+
 def test_confusion_matrix_full_size_checksum():
     """16 x 1024 x 1024 pixels: total count, row sums (label histogram) and column sums (prediction histogram)."""
     from semseg_amd.metrics import SegmentationMetrics

@@ -255,7 +255,8 @@ def test_gemm_with_batchnorm_statistics(ops, dtype, M, N, K, with_res):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,hi,wi,ho,wo,C,act', [(2, 8, 8, 16, 16, 64, 1), (1, 5, 7, 10, 14, 128, 0), (3, 6, 4, 13, 9, 48, 1), (2, 16, 16, 32, 32, 512, 1),
-                                                 (1, 1, 3, 2, 6, 16, 0), (2, 50, 3, 100, 6, 1032, 1)])
+                                                 (1, 1, 3, 2, 6, 16, 0), (2, 50, 3, 100, 6, 1032, 1),
+                                                 (1, 64, 2, 128, 4, 64, 1)])     # thin map: more x2 walker blocks than column-geometry blocks
 def test_batchnorm_of_bilinear_resize(ops, dtype, B, hi, wi, ho, wo, C, act):
     """ss_bn_stats_up / ss_bn_apply_up / ss_bn_bwd_up (LawinHead `cat`: BatchNorm + Mish of a bilinear resize, modules/lawin.py:213-222,
     101-105) against F.interpolate + F.batch_norm (+ F.mish) in fp32, and bit for bit against the unfused pair ss_bilinear_fwd +

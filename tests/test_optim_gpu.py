@@ -99,3 +99,31 @@ def test_adabound_state_dict_round_trip():
     sa, sb = opt_a.state_dict(), opt_b.state_dict()
     for i in sa['state']:
         assert torch.equal(sa['state'][i]['exp_avg_sq'], sb['state'][i]['exp_avg_sq']) and sa['state'][i]['step'] == sb['state'][i]['step'] == 4
+
+
+def test_adabound_load_torch_layout_checkpoint_keeps_constructor_base_lr():
+    """A torch / Lightning 'optimizer_states' entry has no 'base_lrs' (torch_optimizer keeps it as a constructor attribute): after a
+    resume with the scheduler's lr in the group, the bounds must still scale with lr / 1e-3, the constructor's lr (train.py:53-58)."""
+    from semseg_amd.engine import AdaBound
+    from oracle.optim import adabound_step
+    flat = _Flat([3000], 9)
+    opt = AdaBound(flat, lr=1e-3, final_lr=0.1)
+    p_ref, state = flat.data.cpu().clone(), {}
+    g = torch.Generator().manual_seed(3)
+    grad = torch.randn(flat.numel, generator=g)
+    flat.grad.copy_(grad); opt.step()
+    adabound_step(p_ref, grad, state, lr=1e-3, final_lr=0.1, base_lr=1e-3)
+    sd = opt.state_dict()
+    del sd['base_lrs']
+    sd['param_groups'][0]['lr'] = 7e-3                      # where OneCycleLR had moved it when the checkpoint was written
+    flat2 = _Flat([3000], 9)
+    flat2.data.copy_(flat.data)
+    flat2.params = [flat2.data[:3000]]
+    opt2 = AdaBound(flat2, lr=1e-3, final_lr=0.1)
+    opt2.load_state_dict({'state': {0: {'step': 1, 'exp_avg': opt.exp_avg[:3000].clone(), 'exp_avg_sq': opt.exp_avg_sq[:3000].clone()}},
+                          'param_groups': sd['param_groups']})
+    assert opt2.lr == 7e-3 and opt2.base_lr == 1e-3
+    grad = torch.randn(flat.numel, generator=g) * 30
+    flat2.grad.copy_(grad); opt2.step()
+    adabound_step(p_ref, grad, state, lr=7e-3, final_lr=0.1, base_lr=1e-3)
+    assert rel(flat2.data[:3000], p_ref[:3000]) < 1e-6
