@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--table', action='store_true', help='print the per-entry-point time table to stderr')
     ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM / attention timings to stderr')
+    ap.add_argument('--force-comm', action='store_true', help='N = 1: create the RCCL process group (world size 1) and run the bucketed '
+                    'all-reduce path (side stream, hooks, collectives) anyway, so the real backend is exercised on one GPU')
     return ap.parse_args()
 
 
@@ -415,7 +417,11 @@ def main():
     local = local % torch.cuda.device_count()       # rehearsal of N ranks on fewer GPUs (SEMSEG_BENCH_BACKEND=gloo); one rank per GPU otherwise
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    comm_on = world > 1 or a.force_comm
+    if comm_on:
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'), os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0'), os.environ.setdefault('WORLD_SIZE', '1')
         backend = os.environ.get('SEMSEG_BENCH_BACKEND', 'nccl')            # nccl == RCCL over xGMI on ROCm
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
@@ -444,7 +450,7 @@ def main():
     net = net.to(dev).train()
     broadcast_module_state(net)
     flat = FlatParams(net)
-    reducer = GradReducer(flat)
+    reducer = GradReducer(flat, force_comm=a.force_comm)
     opt = AdaBound(flat, lr=1e-3, final_lr=0.1)
     if a.workload == 'dnet':
         crit = DiceLoss(0.5, False, 6)
@@ -484,7 +490,7 @@ def main():
         dt = float(tmax)
     cm = met.compute()                                           # int64 confusion-matrix all-reduce (C2)
     roof, table, comm = None, None, None
-    if world > 1:                                                # one more step with the bucket all-reduces timed on their stream
+    if comm_on:                                                  # one more step with the bucket all-reduces timed on their stream
         reducer.time_comm = True
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -511,7 +517,7 @@ def main():
                 shape_table(trace)
     fence()
     if rank != 0:
-        if world > 1:
+        if comm_on:
             dist.destroy_process_group()
         return
     ms = 1e3 * dt / a.steps
@@ -545,7 +551,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline()
     print(json.dumps(res))
-    if world > 1:
+    if comm_on:
         dist.destroy_process_group()
 
 

@@ -132,3 +132,67 @@ def test_flat_gradient_allreduce_world2_on_one_gpu(tmp_path):
             assert float((g - ref).abs().max()) <= 1e-4 * float(ref.abs().max()), step
         assert float((r['grad_twice'] - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
     assert torch.equal(r0['grad1'], r1['grad1']) and torch.equal(r0['grad_twice'], r1['grad_twice'])
+
+
+# ---------------------------------------------------------------------------- the real backend (RCCL) in a world of one
+def _nccl_worker(rank, world, port, out):
+    import os, sys
+    import torch.distributed as dist
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    from semseg_amd.model import SegFormerLawin
+    from semseg_amd.loss import OhemCrossEntropyLoss
+    from semseg_amd.metrics import SegmentationMetrics
+    from semseg_amd.engine import FlatParams, GradReducer, AdaBound
+    net = SegFormerLawin('B0', 128, 6)
+    det_fill_(net.encoder), det_fill_(net.decoder)
+    net = net.cuda().train()
+    x, lab = det_input('nccl.x', (2, 3, 64, 64)).cuda(), det_labels('nccl.lab', (2, 64, 64), 6, cell=8).cuda()
+    flat = FlatParams(net)
+    res = {'backend': dist.get_backend()}
+
+    def one_step(reducer):
+        torch.manual_seed(11)                                 # the same DropPath / Dropout2d draws in both runs
+        met = SegmentationMetrics(6, ignore_index=0).cuda()
+        flat.zero_grad()
+        logits = net(x)
+        loss = OhemCrossEntropyLoss(0, 0.7, 0.1)(logits, lab)
+        met.update(logits, lab)
+        loss.backward()
+        launched_in_backward = sum(reducer.launched) if reducer is not None else 0
+        scale = reducer.wait() if reducer is not None else 1.0
+        torch.cuda.synchronize()
+        return flat.grad.clone(), met.compute()['Confusion_Matrix'].clone(), launched_in_backward, scale
+
+    g_ref, cm_ref, _, _ = one_step(None)
+    red = GradReducer(flat, bucket_bytes=1 << 20, overlap=True, force_comm=True)
+    res['buckets'], res['side_stream'] = len(red.buckets), red.stream is not None
+    g1, cm1, n1, scale = one_step(red)
+    with torch.no_grad():                                     # a validation forward between two steps must not hold the buckets back
+        net(x)
+    g2, cm2, n2, _ = one_step(red)
+    res.update(grad_equal=bool(torch.equal(g_ref, g1) and torch.equal(g_ref, g2)), cm_equal=bool(torch.equal(cm_ref, cm1) and torch.equal(cm_ref, cm2)),
+               launched_in_backward=(n1, n2), scale=scale, grad_nonzero=float(g_ref.abs().max()) > 0)
+    before = flat.data.clone()
+    AdaBound(flat).step(scale)
+    res['stepped'] = not torch.equal(before, flat.data)
+    torch.save(res, os.path.join(out, 'nccl.pt'))
+    dist.destroy_process_group()
+
+
+def test_rccl_world1_bucketed_allreduce_on_side_stream(tmp_path):
+    """train.py:306-311 (DDP over RCCL): a fresh child process creates the `nccl` process group (world size 1), GradReducer keeps its
+    hook / side-stream / collective path on (force_comm), and one MiT-B0 + Lawin training step plus the confusion-matrix read-out
+    must equal the run without a reducer bit for bit (a one-rank SUM is the identity); every bucket must have been launched from the
+    backward's delivery hooks, also in the step after a no_grad forward."""
+    import os, socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(os.path.join(tmp_path, 'nccl.pt'), weights_only=True)
+    assert r['backend'] == 'nccl' and r['side_stream'] and r['buckets'] >= 3
+    assert r['grad_nonzero'] and r['grad_equal'] and r['cm_equal'] and r['stepped'] and r['scale'] == 1.0
+    assert r['launched_in_backward'] == (r['buckets'], r['buckets'])
