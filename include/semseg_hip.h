@@ -156,6 +156,16 @@ int ss_bn_bwd_classify(int dtype, const void* dseg, int64_t ldd, const void* z, 
                        int64_t ldo, float* dgamma_dbeta, float* dwp, int64_t rows, int C, float* workspace, int64_t ws_bytes,
                        hipStream_t stream);
 
+/* ---- The whole Mix-FFN of a MiT block in one kernel (modules/segformer.py:56-64 MLP.forward: fc2(GELU(dw_conv(fc1(x)))), with the
+ * block's residual and DropPath of :96-99): out = (fc2(GELU(dw3x3(fc1(x) + b1) + bd)) + b2) * keep[image] + res.  The 4C-wide
+ * hidden tensors live in LDS, slice by slice.  x, res (or NULL), out: dense [B*H*W, C] bf16 tokens; w1 [Ch, C], w2 [C, Ch] bf16;
+ * b1, bd [Ch], b2 [C], w9 [9][Ch] (tap-major), keep [B] (or NULL) fp32.  h1_out / a2_out (both or neither): [B*H*W, Ch] bf16 copies of
+ * fc1's output and of the activation, for a backward that reads them.  ss_mixffn_ok: 1 for bf16, C = 64 or 128, Ch = 4C. */
+int ss_mixffn_ok(int dtype, int C, int Ch);
+int ss_mixffn_fwd(int dtype, const void* x, const void* w1, const float* b1, const float* w9, const float* bd, const void* w2,
+                  const float* b2, const void* res, const float* keep, void* out, void* h1_out, void* a2_out, int B, int H,
+                  int W, int C, int Ch, hipStream_t stream);
+
 /* ---- Mix-FFN depthwise 3x3 (+bias, +GELU) on token layout (modules/segformer.py:44-53,64).
  * w9c: weights repacked tap-major [9][C] fp32.  act: 0 none, 1 GELU(erf).
  * bwd: g = dy*act'(dw(x)+b) (written), dw_db = [10][C] fp32 (9 taps + bias); dx = ss_dwconv3_fwd(g, flipped taps). */

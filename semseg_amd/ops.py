@@ -306,6 +306,35 @@ def bn_bwd(dy, z, stats, gamma, beta, act=0, mask=None, rows_per_image=0, traini
 
 
 # ------------------------------------------------------------------ depthwise conv
+def mixffn_ok(x, Ch):
+    return x.is_cuda and bool(lib().ss_mixffn_ok(dt(x), x.shape[1], Ch))
+
+
+def mixffn_fwd(x, w1, b1, w9c, bd, w2, b2, B, H, W, res=None, keep=None, save_hidden=False):
+    """(fc2(GELU(dw3x3(fc1(x) + b1) + bd)) + b2) * keep[image] + res in one kernel -> out [rows, C] (, h1, a2 [rows, Ch] if save_hidden)."""
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    Ch = w1.shape[0]
+    if ld != C or rows != B * H * W or not mixffn_ok(x, Ch):
+        raise ValueError(f'mixffn_fwd: x must be dense bf16 [B*H*W, C] with C in (64, 128) and hidden width 4C (C={C}, Ch={Ch})')
+    for name, t, shape in (('w1', w1, (Ch, C)), ('w2', w2, (C, Ch))):
+        if tuple(t.shape) != shape or t.dtype != x.dtype or not t.is_contiguous():
+            raise ValueError(f'mixffn_fwd: {name} must be contiguous {shape} in the compute dtype')
+    _f32(b1, 'b1', Ch), _f32(bd, 'bd', Ch), _f32(b2, 'b2', C), _f32(w9c, 'w9c', 9 * Ch)
+    if res is not None and (res.shape != x.shape or res.dtype != x.dtype or not res.is_contiguous()):
+        raise ValueError('mixffn_fwd: res must match x')
+    if keep is not None:
+        _f32(keep, 'keep', B)
+    out = torch.empty_like(x)
+    h1 = a2 = None
+    if save_hidden:
+        h1 = torch.empty((rows, Ch), dtype=x.dtype, device=dev)
+        a2 = torch.empty((rows, Ch), dtype=x.dtype, device=dev)
+    check(lib().ss_mixffn_fwd(dt(x), _p(x), _p(w1), _p(b1), _p(w9c), _p(bd), _p(w2), _p(b2), _p(res), _p(keep), _p(out), _p(h1), _p(a2),
+                              B, H, W, C, Ch, _stream()))
+    return (out, h1, a2) if save_hidden else out
+
+
 def dwconv3_fwd(x, w9c, bias, B, H, W, act=0):
     dev = _dev(x)
     rows, C, ld = _mat(x, 'x')
