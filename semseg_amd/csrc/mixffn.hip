@@ -169,20 +169,6 @@ __global__ __launch_bounds__(256, 2) void mixffn_fwd_kernel(MixArgs a, int ntile
 
         for (int s = 0; s < nsl; ++s) {
             const int sn = s + 1 < nsl ? s + 1 : 0;    // the slice after this one (of the next tile, at the end)
-            if (s == nsl - 1 && tile + (int)gridDim.x < ntiles) {
-                // the next tile's halo pixels start travelling to L2 a whole slice before their fragment loads
-                constexpr int LPP = C * 2 / 128;       // 128-byte lines per pixel
-                const int nt = tile + (int)gridDim.x;
-                const int nimg = (int)fdiv((unsigned)nt, d_tpi), nrem = nt - nimg * (int)d_tpi.d;
-                const int nty = (int)fdiv((unsigned)nrem, d_tx), ntx = nrem - nty * (int)d_tx.d;
-#pragma unroll
-                for (int j = 0; j < (IP * LPP + 255) / 256; ++j) {
-                    const int idx = tid + j * 256, p = idx / LPP, ln = idx - p * LPP, iy = p / IW, ix = p - iy * IW;
-                    int gy = nty * TH - 1 + iy, gx = ntx * TW - 1 + ix;
-                    gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy); gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-                    if (p < IP) prefetch_dword(a.x + (((int64_t)nimg * a.H + gy) * a.W + gx) * C + ln * 64, pf_lds);
-                }
-            }
             // ---- A: expand
 #pragma unroll
             for (int q = 0; q < RTW; ++q) {

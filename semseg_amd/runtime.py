@@ -66,6 +66,12 @@ class GradAwareFunction(torch.autograd.Function):
             _tls.recording = prev
 
 
+def recording():
+    """Inside a ``GradAwareFunction.forward``: False when the caller runs under ``torch.no_grad()`` (nothing needs to be kept for a
+    backward), True otherwise (also when unknown)."""
+    return getattr(_tls, 'recording', None) is not False
+
+
 def expect_grads(ctx, params, first):
     """Forward-side twin of ``deliver_grads``: tells whoever tracks gradient arrival (engine.GradReducer, through the parameter's
     ``_ss_grad_expect`` callback) that this graph node will deliver one gradient to each of its parameters, ``params`` being the

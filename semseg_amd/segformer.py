@@ -10,7 +10,7 @@ import torch
 from torch import nn, Tensor
 
 from . import ops, weightprep
-from .runtime import compute_dtype_for, as_tokens_nhwc, drop_path_keep, deliver_grads, expect_grads, GradAwareFunction
+from .runtime import compute_dtype_for, as_tokens_nhwc, drop_path_keep, deliver_grads, expect_grads, GradAwareFunction, recording
 from .shapes import MIT_VARIANTS, MIT_HEADS, MIT_SR, MIT_PATCH
 
 
@@ -116,11 +116,20 @@ def attn_backward(P, S, dout, B, h, w, head, sr, keep=None):
 FUSED_DW_MIN_PIXELS = 4096        # maps at least this large take the one-pass depthwise backward (measured crossover: 32 x 32 loses, 64 x 64 wins)
 
 
+FUSED_MIXFFN = True               # C = 64 / 128 in bf16 (MiT stages 1-2): fc1 -> depthwise + GELU -> fc2 as ONE kernel, hidden tensors on chip
+
+
 def mlp_forward(P, x, B, h, w, res=None, keep=None):
     T = x.dtype
-    h1 = ops.gemm_nt(x, w_fwd(P['fc1.weight'], T), bias=P['fc1.bias'])
-    Ch = h1.shape[1]
     w9c = w_taps(P['dw_conv.dw_conv.weight'])
+    if FUSED_MIXFFN and ops.mixffn_ok(x, P['fc1.weight'].shape[0]):
+        # one launch; a forward that records a graph also stores h1 and a2 (the backward below reads them), inference stores neither
+        args = (x, w_fwd(P['fc1.weight'], T), P['fc1.bias'], w9c, P['dw_conv.dw_conv.bias'], w_fwd(P['fc2.weight'], T), P['fc2.bias'], B, h, w)
+        if recording():
+            out, h1, a2 = ops.mixffn_fwd(*args, res=res, keep=keep, save_hidden=True)
+            return out, {'x': x, 'h1': h1, 'a2': a2, 'w9c': w9c}
+        return ops.mixffn_fwd(*args, res=res, keep=keep), {'x': x, 'w9c': w9c}
+    h1 = ops.gemm_nt(x, w_fwd(P['fc1.weight'], T), bias=P['fc1.bias'])
     a2 = ops.dwconv3_fwd(h1, w9c, P['dw_conv.dw_conv.bias'], B, h, w, act=1)
     out = ops.gemm_nt(a2, w_fwd(P['fc2.weight'], T), bias=P['fc2.bias'], res=res, rowscale=keep,
                       rows_per_scale=h * w if keep is not None else 0)
