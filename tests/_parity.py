@@ -2,7 +2,8 @@
 
 ``rel`` / ``rel_l2`` return a ``Measured`` float: comparing it with a tolerance (``assert rel(a, b) < 1e-4``) stores the measured
 value, the tolerance and the call site.  At the end of a pytest session ``dump()`` (called from conftest.py) writes the worst value
-per call site to ``gpurun_out/parity_errors.json``; DESIGN.md's table of measured errors is that file.
+per call site to ``gpurun_out/parity_errors.json`` (replacing the file: one session, one record); DESIGN.md's table of measured
+errors is that file.
 """
 import inspect
 import json
@@ -74,7 +75,9 @@ def dump(path=None):
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         old = {}
-        if os.path.exists(path):
+        # one pytest session = one record: a previous file is replaced, not merged (stale worst cases of older trees would survive);
+        # PARITY_MERGE=1 keeps it for a suite that is run file by file
+        if os.environ.get('PARITY_MERGE') == '1' and os.path.exists(path):
             with open(path) as f:
                 old = json.load(f)
         old.update(_LOG)
