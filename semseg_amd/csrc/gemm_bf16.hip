@@ -309,6 +309,7 @@ int64_t ss_fast_nt_stat_tiles(const FastGemm& p) { return cdiv(p.M, big_enabled(
 int ss_fast_nt_launch(FastGemm p, hipStream_t st) {
     if (ss_stream_nt_ok(p)) return ss_stream_nt_launch(p, st);
     if (big_enabled() && ss_big_nt_ok(p)) return ss_big_nt_launch(p, st);
+    if (big_enabled() && ss_wide_nt_ok(p)) return ss_wide_nt_launch(p, st);
     const bool narrow = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 1024);
     if (narrow) {
         p.ntn = (int)cdiv(p.N, 64);

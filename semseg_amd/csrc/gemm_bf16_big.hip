@@ -157,6 +157,96 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(FastGemm p) {
     if (p.stat_ws) nt_tile_stats<BN, RPP, 512>(p, smem, sx, sq, erow, ech, m0 / BM, n0, tid);
 }
 
+// Wide form for outputs whose width is a multiple of 320 but not of 256 (the N = 320 projections of MiT stage 3): 256 x 320 tiles, the
+// 8 waves as 4 (m) x 2 (n) with 64 x 160 each (10 accumulators of 32 x 32).  The whole output row panel is ONE tile, so the activation
+// operand is read once (the 128-column tile kernel these shapes ran on read it three times and moves 64 flop per byte into LDS; this
+// tile moves 142).  Two stages of 72 KiB; the epilogue is per wave through 2 KiB strips (an [m][n] image of the tile would not fit).
+template <int TB>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_256w_kernel(FastGemm p) {
+    constexpr int BM = 256, BN = 64 * TB, BK = 64;
+    constexpr int IMGA = BM * BK * 2, IMGB = BN * BK * 2, STAGE = IMGA + IMGB;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int wg = xcd_remap_big(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(wg / p.ntn) * BM;
+    const int n0 = (wg % p.ntn) * BN;
+    const int nk = (int)(p.K / BK);
+
+    const bf16* pa[4]; const bf16* pb[TB];
+    auto src = [&](int q, int& row, int& chunk) {      // piece q of an image: this lane's slot -> (row, 16-byte chunk)
+        const int R = q * 4 + (lane >> 4);
+        const int x = (lane & 15) ^ (R & 15);
+        row = 2 * R + (x >> 3); chunk = x & 7;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, chunk; src(wave * 4 + i, row, chunk);
+        int64_t ra = m0 + row; if (ra >= p.M) ra = p.M - 1;
+        pa[i] = p.A + ra * p.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+        int row, chunk; src(wave * TB + i, row, chunk);
+        pb[i] = p.B + (int64_t)(n0 + row) * p.ldb + chunk * 8;
+    }
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void*)(pa[i] + kt * BK), (lds_void*)(st + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void*)(pb[i] + kt * BK), (lds_void*)(st + IMGA + (wave * TB + i) * 1024), 16, 0, 0);
+    };
+
+    floatx16 acc[2][TB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // tile kt has landed; nobody still reads the other stage
+        if (kt + 1 < nk) issue(kt + 1);
+        const bf16* As = (const bf16*)(smem + (kt & 1) * STAGE);
+        const bf16* Bs = (const bf16*)(smem + (kt & 1) * STAGE + IMGA);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 fa[2], fb[TB];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[a] = *(const bf16x8*)(As + big_slot(wm * 64 + a * 32 + li, ks * 2 + lh) * 8);
+#pragma unroll
+            for (int b = 0; b < TB; ++b) fb[b] = *(const bf16x8*)(Bs + big_slot(wn * 32 * TB + b * 32 + li, ks * 2 + lh) * 8);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < TB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                   // the stages are free: every wave takes 2 KiB of them for its epilogue strip
+    nt_epilogue_wave<2, TB>(acc, p, smem + wave * 2048, m0, n0, wm * 64, wn * 32 * TB, lane);
+}
+
+bool ss_wide_nt_ok(const FastGemm& p) {
+    if (p.N % 320 || p.N % 256 == 0 || p.K % 64 || p.K < 256 || p.stat_ws || p.w2 || p.pm.side) return false;
+    return cdiv(p.M, 256) * (p.N / 320) >= 128;
+}
+
+int ss_wide_nt_launch(FastGemm p, hipStream_t st) {
+    p.ntn = p.N / 320; p.dbg = 0;
+    hipLaunchKernelGGL(gemm_nt_bf16_256w_kernel<5>, dim3((unsigned)(p.ntn * cdiv(p.M, 256))), dim3(512), 0, st, p);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
 // LDS-DMA by hand for the persistent kernel.  hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of any LDS access once an
 // LDS-DMA builtin is in flight (it cannot tell the stages apart), which would make every k-iteration wait for the prefetch it has
 // just issued; instructions it does not see are waited for by the kernel itself.  M0 (the LDS destination) is written right before

@@ -141,12 +141,152 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(FastGemm p) {
         }
 }
 
+// The same kernel for outputs one of whose sides is a multiple of 320 but not of 256 (MiT stage 3: 320 x 1280 and 1280 x 320 weight
+// gradients, which the 256-tile plan refuses as 60 % padding): 256 x 320 tiles (waves 4 x 2, 64 x 160 each) or 320 x 256 tiles
+// (waves 2 x 4, 160 x 64 each).  Operand rows in LDS are BM*2 / BN*2 bytes (512 / 640: multiples of 128, so the rows of a transpose
+// block share their banks); 16-byte slot s of row r lives at s ^ ((r & 1) << 2) -- odd rows shifted by 64 bytes inside their 128-byte
+// block, which is what the four-row transpose read needs -- applied to the fill's source address and to the fragment reads.
+template <int TA, int TB, int WM, int WN>
+__global__ __launch_bounds__(512) void gemm_tn_bf16_wide_kernel(FastGemm p) {
+    constexpr int BM = WM * TA * 32, BN = WN * TB * 32, BK = 64;
+    constexpr int PA = BM * 2, PB = BN * 2;            // row pitches (bytes)
+    constexpr int IMGA = BK * PA, IMGB = BK * PB, STAGE = IMGA + IMGB;
+    constexpr int QA = IMGA / 1024 / 8, QB = IMGB / 1024 / 8;          // 1 KiB fill pieces per wave
+    static_assert(WM * WN == 8 && IMGA % 8192 == 0 && IMGB % 8192 == 0, "eight waves, whole pieces per wave");
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+    const int vid = xcd_remap_tnb(blockIdx.x, gridDim.x);
+    const int split = vid / p.ntiles, wg = vid % p.ntiles;
+    const int m0 = (wg / p.ntn) * BM, n0 = (wg % p.ntn) * BN;
+    const int64_t kbeg = (int64_t)split * p.k_per_split;
+    const int64_t kend = kbeg + p.k_per_split < p.K ? kbeg + p.k_per_split : p.K;
+    const int nk = (int)((kend - kbeg) / BK);
+
+    const bf16* pa[QA]; const bf16* pb[QB];
+#pragma unroll
+    for (int i = 0; i < QA; ++i) {                     // this lane fills physical slot g of the A image: row g / (BM/8), slot g % (BM/8)
+        const int g = (wave * QA + i) * 64 + lane, row = g / (BM / 8), ls = (g % (BM / 8)) ^ ((row & 1) << 2);
+        const int ca = m0 + ls * 8 < p.M ? m0 + ls * 8 : m0;
+        pa[i] = p.A + (kbeg + row) * p.lda + ca;
+    }
+#pragma unroll
+    for (int i = 0; i < QB; ++i) {
+        const int g = (wave * QB + i) * 64 + lane, row = g / (BN / 8), ls = (g % (BN / 8)) ^ ((row & 1) << 2);
+        const int cb = n0 + ls * 8 < p.N ? n0 + ls * 8 : n0;
+        pb[i] = p.B + (kbeg + row) * p.ldb + cb;
+    }
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < QA; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void*)(pa[i] + (int64_t)kt * BK * p.lda), (lds_void*)(st + (wave * QA + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < QB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void*)(pb[i] + (int64_t)kt * BK * p.ldb), (lds_void*)(st + IMGA + (wave * QB + i) * 1024), 16, 0, 0);
+    };
+
+    floatx16 acc[TA][TB];
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // transpose-read addressing as in gemm_tn_bf16_256_kernel; row = 16 ks + 8 lh + tq (+4 for the upper half: same parity, same shift)
+    const int l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3, gsel = (lane >> 4) & 1;
+    const int sub_off = (gsel * 2 + (tp >> 1)) * 16 + (tp & 1) * 8;
+    auto trfrag = [&](const char* img, int pitch, int ks, int colbase) {       // colbase: multiple of 32
+        const char* a0 = img + (ks * 16 + 8 * lh + tq) * pitch + (((colbase >> 3) ^ ((tq & 1) << 2)) << 4) + sub_off;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 4 * pitch));
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+        return f;
+    };
+
+    const bool do_cs = p.colsum_ws && n0 == 0 && wn == 0;     // column sums of A (the bias gradient): the wn = 0 waves sum their fragments
+    float cs[TA];
+#pragma unroll
+    for (int a = 0; a < TA; ++a) cs[a] = 0.f;
+    float keep_mul = p.rowscale ? 0.f : 1.f;
+    if (nk > 0) issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1);
+        const char* As = smem + (kt & 1) * STAGE;
+        const char* Bs = As + IMGA;
+        const float kv = p.rowscale ? p.rowscale[(kbeg + (int64_t)kt * BK) / p.rows_per_scale] : 1.f;
+        if (kv != 0.f) keep_mul = kv;
+#pragma unroll
+        for (int ks = 0; ks < (kv != 0.f ? BK / 16 : 0); ++ks) {
+            bf16x8 fa[TA], fb[TB];
+#pragma unroll
+            for (int a = 0; a < TA; ++a) fa[a] = trfrag(As, PA, ks, wm * TA * 32 + a * 32);
+#pragma unroll
+            for (int b = 0; b < TB; ++b) fb[b] = trfrag(Bs, PB, ks, wn * TB * 32 + b * 32);
+            if (do_cs) {
+                const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+                for (int a = 0; a < TA; ++a)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16x2 pr = {fa[a][2 * e], fa[a][2 * e + 1]};
+                        cs[a] = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, cs[a], false);
+                    }
+            }
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int b = 0; b < TB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    if (do_cs) {
+#pragma unroll
+        for (int a = 0; a < TA; ++a) {
+            const float t = (cs[a] + __shfl_xor(cs[a], 32)) * keep_mul;
+            const int m = m0 + wm * TA * 32 + a * 32 + li;
+            if (lh == 0 && m < p.M) p.colsum_ws[(int64_t)split * p.M + m] = t;
+        }
+    }
+    float* C = (float*)p.C + (int64_t)split * p.M * p.N;
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            const int col = n0 + wn * TB * 32 + b * 32 + li;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TA * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < p.M) C[(int64_t)row * p.N + col] = acc[a][b][r] * keep_mul;
+            }
+        }
+}
+
+// tile shape of the big TN kernels for an [M, N] output: 256 x 256, or a 320-wide side where that side is a multiple of 320 (and not
+// of 256) and the other one suits 256 / 320 rows.  0 = none (the 128-tile kernel takes the shape).
+static int tn_tile_shape(int64_t M, int64_t N, int* bm, int* bn) {
+    auto fits = [](int64_t x, int t) { return x >= t && (double)(cdiv(x, t) * t) <= 1.25 * (double)x; };
+    if (M < 256 || N < 256 || M % 8 || N % 8) return 0;
+    if ((double)(cdiv(M, 256) * 256) * (double)(cdiv(N, 256) * 256) <= 1.5 * (double)M * (double)N) { *bm = 256; *bn = 256; return 1; }
+    if (N % 320 == 0 && fits(M, 256)) { *bm = 256; *bn = 320; return 2; }
+    if (M % 320 == 0 && fits(N, 256)) { *bm = 320; *bn = 256; return 3; }
+    return 0;
+}
+
 // Plan for the 256-tile kernel: whole-chip launches of one workgroup per CU (tiles x splits <= 256, or several full rounds when the
 // output alone has more tiles), splits of whole k-tiles.  False when the shape does not suit the tile.
 bool ss_big_tn_plan(int64_t M, int64_t N, int64_t R, int* nsplit, int64_t* rps) {
-    if (M < 256 || N < 256 || M % 8 || N % 8 || R % 64 || R < 4096) return false;
-    const int64_t tm = cdiv(M, 256), tn = cdiv(N, 256), tiles = tm * tn;
-    if ((double)(tm * 256) * (double)(tn * 256) > 1.5 * (double)M * (double)N) return false;     // too much of the tiles would be padding
+    int bm, bn;
+    if (R % 64 || R < 4096 || !tn_tile_shape(M, N, &bm, &bn)) return false;
+    const int64_t tiles = cdiv(M, bm) * cdiv(N, bn);
     int64_t s = tiles >= 256 ? 1 : 256 / tiles;
     const int64_t maxs = R / (8 * 64);                 // >= 8 k-tiles per split
     if (s > maxs) s = maxs;
@@ -159,15 +299,21 @@ bool ss_big_tn_plan(int64_t M, int64_t N, int64_t R, int* nsplit, int64_t* rps) 
 }
 
 bool ss_big_tn_ok(const FastGemm& p, int nsplit) {
-    if (!aligned16(p.A) || !aligned16(p.B) || p.lda % 8 || p.ldb % 8 || p.M % 8 || p.N % 8) return false;
-    if (p.M < 256 || p.N < 256 || p.K % 64 || p.k_per_split % 64) return false;
-    return cdiv(p.M, 256) * cdiv(p.N, 256) * nsplit < (1LL << 30);
+    int bm, bn;
+    if (!aligned16(p.A) || !aligned16(p.B) || p.lda % 8 || p.ldb % 8 || !tn_tile_shape(p.M, p.N, &bm, &bn)) return false;
+    if (p.K % 64 || p.k_per_split % 64) return false;
+    return cdiv(p.M, bm) * cdiv(p.N, bn) * nsplit < (1LL << 30);
 }
 
 int ss_big_tn_launch(FastGemm p, int nsplit, hipStream_t st) {
-    p.ntn = (int)cdiv(p.N, 256);
-    p.ntiles = (int)(p.ntn * cdiv(p.M, 256));
-    hipLaunchKernelGGL(gemm_tn_bf16_256_kernel, dim3((unsigned)(p.ntiles * nsplit)), dim3(512), 0, st, p);
+    int bm = 256, bn = 256;
+    const int shape = tn_tile_shape(p.M, p.N, &bm, &bn);
+    p.ntn = (int)cdiv(p.N, bn);
+    p.ntiles = (int)(p.ntn * cdiv(p.M, bm));
+    const dim3 grid((unsigned)(p.ntiles * nsplit));
+    if (shape == 2) hipLaunchKernelGGL((gemm_tn_bf16_wide_kernel<2, 5, 4, 2>), grid, dim3(512), 0, st, p);
+    else if (shape == 3) hipLaunchKernelGGL((gemm_tn_bf16_wide_kernel<5, 2, 2, 4>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(gemm_tn_bf16_256_kernel, grid, dim3(512), 0, st, p);
     SS_LAUNCH_CHECK();
     return 0;
 }

@@ -87,6 +87,8 @@ bool ss_skinny_tn_ok(const void* B, int64_t ldb, int64_t M, int64_t N);
 int ss_skinny_tn_launch(const FastGemm& p, int nsplit, hipStream_t st);
 bool ss_stream_nt_ok(const FastGemm& p);                 // gemm_bf16_stream.hip: K = 64 / 128, N <= 256, every wave a pipeline of its own
 int ss_stream_nt_launch(FastGemm p, hipStream_t st);
+bool ss_wide_nt_ok(const FastGemm& p);                   // gemm_bf16_big.hip: 256 x 320 tiles for N % 320 == 0 (MiT stage 3)
+int ss_wide_nt_launch(FastGemm p, hipStream_t st);
 bool ss_big_nt_ok(const FastGemm& p);
 int ss_big_nt_launch(FastGemm p, hipStream_t st);
 int ss_big_nt2_launch(FastGemm p, hipStream_t st);      // the two-product form (p.w2 set): always the one-tile-per-workgroup kernel

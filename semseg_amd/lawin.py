@@ -223,8 +223,24 @@ def head_backward(P, S, dseg, E):
         dzl, dgb = ops.bn_bwd(dfused, S['zl'], S['stl'], P['low_level_fuse.bn.weight'], P['low_level_fuse.bn.bias'], act=1, mask=mask,
                               rows_per_image=rpi4, training=training)
     bn_grads('low_level_fuse.bn', dgb)
-    G['low_level_fuse.conv.weight'] = ops.gemm_tn(dzl, S['cat2'])
-    dcat2 = ops.gemm_nt(dzl, w_bwd(P['low_level_fuse.conv.weight'], T), out=_rows_on_lines(dzl.shape[0], S['cat2'].shape[1], T, dzl.device))
+    Kc2 = S['cat2'].shape[1]
+    if T == torch.bfloat16 and Kc2 % 8 == 0 and 320 < Kc2 <= 576 and E % 64 == 0 and S['cat2'].stride(0) == 576:
+        # E + 48 = 560 columns suit neither the 256- nor the 320-column tile kernels (they ran on 128-column tiles at 0.56 PFLOP/s):
+        # both gradients run as a 320-column product plus a 256-column one over the concat padded to 576 columns (zero weight rows
+        # / the concat's own zero columns behind column 560); dzl is read twice, the products run on the wide tiles
+        wt = weightprep.transpose_padded(P['low_level_fuse.conv.weight'], E, Kc2, T, 576)          # [576, E]
+        dfull = torch.empty((dzl.shape[0], 576), dtype=T, device=dzl.device)
+        ops.gemm_nt(dzl, wt[:320], out=dfull[:, :320])
+        ops.gemm_nt(dzl, wt[320:], out=dfull[:, 320:])
+        dcat2 = dfull[:, :Kc2]
+        cat2f = S['cat2'].as_strided((S['cat2'].shape[0], 576), (576, 1))                        # the padded buffer the forward filled
+        Gl = torch.empty((E, 576), dtype=torch.float32, device=dzl.device)
+        ops.gemm_tn(dzl, cat2f[:, :320], out=Gl[:, :320])
+        ops.gemm_tn(dzl, cat2f[:, 320:], out=Gl[:, 320:])
+        G['low_level_fuse.conv.weight'] = Gl[:, :Kc2]                                             # row-strided: deliver_grads takes it as it is
+    else:
+        G['low_level_fuse.conv.weight'] = ops.gemm_tn(dzl, S['cat2'])
+        dcat2 = ops.gemm_nt(dzl, w_bwd(P['low_level_fuse.conv.weight'], T), out=_rows_on_lines(dzl.shape[0], Kc2, T, dzl.device))
     dc1 = dcat2[:, E:]
     G['linear_c1.proj.weight'], G['linear_c1.proj.bias'] = ops.gemm_tn(dc1, t[0], colsum=True)
     dt = [ops.gemm_nt(dc1, w_bwd(P['linear_c1.proj.weight'], T)), None, None, None]
