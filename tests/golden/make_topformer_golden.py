@@ -47,3 +47,37 @@ for k, v in feats.items():                      # the two coarsest injected maps
         save['feat.' + k] = v.numpy()
 np.savez_compressed(os.path.join(HERE, f'topformer_{tag}.npz'), **save)
 print(tag, 'logits', tuple(out.shape), 'params', sum(p.numel() for p in net.parameters()), 'keys', len(manifest))
+
+# ---- one training step (append `train` as the second argument): train-mode forward (batch-statistic BatchNorm), OHEM cross-entropy as
+# train.py:61-67 configures it, backward; logits, loss, a sample of gradients from every part of the network and the BatchNorm running
+# statistics after the step.  Written to topformer_<tag>_train.npz.
+if len(sys.argv) > 2 and sys.argv[2] == 'train':
+    from semseg_amd.detinit import det_labels  # noqa: E402
+    from loss.seg_loss import OhemCrossEntropyLoss  # noqa: E402  (reference)
+    net.train()
+    for p in net.parameters():
+        p.grad = None
+    xt = det_input('top.xt', (2, 3, 128, 192))
+    lab = det_labels('top.lab', (2, 128, 192), 6, cell=8)
+    logits = net(xt)
+    loss = OhemCrossEntropyLoss(ignore_index=0, threshold=0.7, min_kept=0.1)(logits, lab)
+    loss.backward()
+    tsave = {'logits': logits.detach().numpy(), 'loss': loss.detach().numpy()}
+    names = [n for n, p in net.named_parameters() if p.grad is not None]
+    missing = [n for n, p in net.named_parameters() if p.grad is None]
+    # every parameter's gradient as its L2 norm (cheap, catches a wrong chain anywhere) and a sample of full tensors
+    tsave['gradnorm.names'] = np.array(names)
+    tsave['gradnorm.values'] = np.array([float(dict(net.named_parameters())[n].grad.norm()) for n in names], dtype=np.float64)
+    pick = [n for n in names if any(s in n for s in ('stem.', 'stage_1.resblock_2.', 'stage_4.resblock_1.', 'extractor_1.', 'extractor_4.mlp',
+                                                     'post_stages.stage_1.', 'post_stages.stage_4.', 'head.', 'classifier.'))]
+    for n in pick:
+        g_ = dict(net.named_parameters())[n].grad
+        if g_.numel() <= 40000:
+            tsave['grad.' + n] = g_.numpy()
+    for k, v in net.state_dict().items():
+        if k.endswith('running_mean') or k.endswith('running_var') or k.endswith('num_batches_tracked'):
+            if any(s in k for s in ('stem.', 'stage_2.resblock_1.', 'extractor_2.', 'post_stages.stage_3.', 'head.')):
+                tsave['after.' + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, f'topformer_{tag}_train.npz'), **tsave)
+    print(tag, 'train: loss', float(loss), 'params with grad', len(names), 'without', missing, 'full gradients kept', sum(k.startswith('grad.') for k in tsave),
+          'buffers', sum(k.startswith('after.') for k in tsave))
