@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--table', action='store_true', help='print the per-entry-point time table to stderr')
     ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM / attention timings to stderr')
+    ap.add_argument('--train', action='store_true', help='topformer: the training step of train.py:45-52 (TopFormer-B, fwd + OHEM-CE + confusion '
+                    'matrix + bwd + grad all-reduce + AdaBound; default 1024x1024, batch 16) instead of configs[3] inference')
     ap.add_argument('--force-comm', action='store_true', help='N = 1: create the RCCL process group (world size 1) and run the bucketed '
                     'all-reduce path (side stream, hooks, collectives) anyway, so the real backend is exercised on one GPU')
     return ap.parse_args()
@@ -438,9 +440,12 @@ def main():
 
     T = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     set_compute_dtype(T)
-    if a.workload == 'topformer':
+    if a.workload == 'topformer' and not a.train:
         return topformer_inference(a, world, rank, dev)
-    if a.workload == 'dnet':
+    if a.workload == 'topformer':
+        from semseg_amd.topformer import TopFormerModel
+        net = det_fill_(TopFormerModel(6, 'B', head_cfg=frozenset({'alias': a.head}.items())))
+    elif a.workload == 'dnet':
         from semseg_amd.decoder import DNet
         from semseg_amd.loss import DiceLoss
         net = det_fill_(DNet(3, 6, embed_dim=256, stem_code='T'))
@@ -521,11 +526,14 @@ def main():
             dist.destroy_process_group()
         return
     ms = 1e3 * dt / a.steps
-    res = {'metric': f'train images/sec @{a.size}x{a.size} (DNet ConvNeXt-T)' if a.workload == 'dnet' else f'train images/sec @{a.size}x{a.size} (MiT-{a.variant}+Lawin)', 'value': a.batch * world * a.steps / dt, 'unit': 'images/s',
+    what = {'dnet': 'DNet ConvNeXt-T', 'topformer': f'TopFormer-B + {a.head} head'}.get(a.workload, f'MiT-{a.variant}+Lawin')
+    res = {'metric': f'train images/sec @{a.size}x{a.size} ({what})', 'value': a.batch * world * a.steps / dt, 'unit': 'images/s',
            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
            'config': {'workload': (f'configs[2] per-GPU step: DNet(ConvNeXt-T + Decoder(embed 256), 6 cls) training step (fwd + Dice + confusion '
                                    f'matrix + bwd + grad all-reduce + AdaBound), {a.size}x{a.size}') if a.workload == 'dnet' else
+                                  (f'train.py:45-52 model: TopFormer-B + {a.head} head (6 cls) training step (fwd + OHEM-CE + confusion matrix + bwd + '
+                                   f'grad all-reduce + AdaBound), {a.size}x{a.size}') if a.workload == 'topformer' else
                                   f'configs[1]: SegFormer MiT-{a.variant} + LawinHead({a.embed}, 6 cls) training step '
                                   f'(fwd + {"OHEM-CE + Dice" if a.loss == "ce_dice" else "OHEM-CE"} + confusion matrix + bwd + grad all-reduce + AdaBound), {a.size}x{a.size}',
                       'per_gpu_batch': a.batch, 'global_batch': a.batch * world, 'parallelism': f'dp{world}',
@@ -548,7 +556,7 @@ def main():
                 rate = f"{r / 1e12:8.1f} TFLOP/s" if t['bound'] == 'mfma' else f"{r / 1e9:8.0f} GB/s"
             print(f"{name:28s} {t['calls']:5d} calls {t['ms']:9.2f} ms {100 * t['ms'] / tot:5.1f}% {rate}", file=sys.stderr)
         print(f"{'(sum of entry points)':28s} {tot:22.2f} ms", file=sys.stderr)
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and a.workload == 'mit_lawin':       # the CPU leg times the headline workload only
         res['cpu_baseline'] = cpu_baseline()
     print(json.dumps(res))
     if comm_on:

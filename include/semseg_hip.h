@@ -475,6 +475,40 @@ int ss_inject_fuse_sum(int dtype, const void* local, int64_t ldl, const void* ga
                        int n_extra, const void* const* extra, const int64_t* extra_ld, const int* extra_h, const int* extra_w, void* out,
                        int64_t ldo, int B, int hl, int wl, int hg, int wg, int C, hipStream_t stream);
 
+/* ---- TopFormer training step (train.py:45-52 trains TopFormerModel('B', head refiner); modules/topformer.py in train mode):
+ * the backward-side kernels the inference path has no use for.
+ * ss_dwconvk_dgrad: data gradient of ss_dwconvk_fwd for stride 1 / 2 and the asymmetric AutoPadding (modules/layers.py:146-164;
+ *   InvertedResidual conv_dw, modules/topformer.py:166-184): g [B*Ho*Wo][C] -> dx [B*H*W][C]; wkkc as the forward's.  C % 8 == 0.
+ * ss_dwconvk_wgrad_s: the weight / bias gradient for the same geometry, dw_db = [(k*k + 1)][C] fp32 (taps tap-major, then the bias
+ *   gradient); k in {3, 5}; workspace >= 256 * (k*k+1) * C floats.
+ * ss_avgpool_bwd: gradient of ss_avgpool (PyramidPoolAgg, modules/topformer.py:527-552); g may be a channel slice (row pitch ldg).
+ * ss_act_bwd: dx = dy * act'(.) from the activation's OUTPUT y (2 ReLU, 3 ReLU6 -- open interval like torch's hardtanh backward --,
+ *   5 sigmoid, 0 copy).  ss_mul: out = a * b (InjectionDotSum's product, modules/topformer.py:640-673, and its two gradients). */
+int ss_dwconvk_dgrad(int dtype, const void* g, const float* wkkc, void* dx, int B, int H, int W, int C, int k, int stride, int pad_top,
+                     int pad_left, int Ho, int Wo, hipStream_t stream);
+int ss_dwconvk_wgrad_s(int dtype, const void* g, const void* x, float* dw_db, int B, int H, int W, int C, int k, int stride, int pad_top,
+                       int pad_left, int Ho, int Wo, float* workspace, int64_t ws_bytes, hipStream_t stream);
+int ss_avgpool_bwd(int dtype, const void* g, int64_t ldg, void* dx, int64_t ldx, int B, int H, int W, int C, int win, hipStream_t stream);
+int ss_act_bwd(int dtype, const void* dy, const void* y, void* dx, int64_t n, int act, hipStream_t stream);
+int ss_mul(int dtype, const void* a, const void* b, void* out, int64_t n, hipStream_t stream);
+/* RefinerHead in train mode (modules/heads.py:22-39, :173-269).
+ * ss_simam_bwd: gradient of ss_simam_apply w.r.t. x (through the mean and the variance as well) and w.r.t. the learnable k
+ *   (dk, one float, += when accumulate_dk); moments as ss_image_moments(x); sums: [images][2][C] fp32 scratch;
+ *   workspace >= images * 1024 * 2 * C floats.
+ * ss_groupnorm_fwd / _bwd: nn.GroupNorm(groups, groups*cg) with an optional sigmoid in front (pre_act 5: the 'CAN' order of the group
+ *   conv, :200-222) on fp32 maps [images * rows_per_image][ncol], channel g*cg + j in column g*pitch + j, other columns padding (written
+ *   as zero).  fwd: moments = ss_image_moments(x, pre_act) -> coef [images][2][ncol], stats [images][groups][2] (mean, rstd), y.
+ *   bwd: dx, dgamma_dbeta [2][groups*cg]; scratch >= images * 5 * ncol floats; workspace >= images * 1024 * 2 * ncol floats. */
+int ss_simam_bwd(int dtype, const void* dy, int64_t ldd, const void* x, int64_t ldx, const float* moments, const float* k, void* dx,
+                 int64_t ldo, float* dk, int accumulate_dk, float* sums, int64_t rows_per_image, int C, int images, float* workspace,
+                 int64_t ws_bytes, hipStream_t stream);
+int ss_groupnorm_fwd(const float* x, int64_t ldx, const float* moments, int64_t rows_per_image, int images, int groups, int cg, int pitch,
+                     int ncol, float eps, const float* gamma, const float* beta, int pre_act, float* coef, float* stats, float* y,
+                     int64_t ldy, hipStream_t stream);
+int ss_groupnorm_bwd(const float* dy, int64_t ldd, const float* x, int64_t ldx, const float* stats, const float* gamma,
+                     int64_t rows_per_image, int images, int groups, int cg, int pitch, int ncol, int pre_act, float* dx, int64_t ldo,
+                     float* dgamma_dbeta, float* scratch, float* workspace, int64_t ws_bytes, hipStream_t stream);
+
 /* ---- TopFormer RefinerHead, inference (modules/heads.py:22-39 SimpleAttention, :42-60 AttentionUniRes, :173-269 RefinerHead;
  * core/models.py:52-72,99-115).  Token matrices [images * rows_per_image, C], all reductions in a fixed order.
  * ss_image_moments: moments[img][0][c] = mean over the image's rows of f(x[:, c]), [img][1][c] = sum (f(x) - mean)^2;

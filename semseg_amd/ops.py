@@ -392,7 +392,7 @@ def mit_attn_fwd(q, kv, B, N, Nk, heads, scale=None):
     return o, lse
 
 
-def mit_attn_bwd(q, kv, o, dout, lse, B, N, Nk, heads):
+def mit_attn_bwd(q, kv, o, dout, lse, B, N, Nk, heads, scale=None):
     dev = _dev(q)
     rows, C, ld = _mat(q, 'q')
     D = C // heads
@@ -406,8 +406,8 @@ def mit_attn_bwd(q, kv, o, dout, lse, B, N, Nk, heads):
     dkv = torch.empty_like(kv)
     nbytes = lib().ss_mit_attn_bwd_workspace(dt(q), B, N, Nk, heads, D)
     ws = workspace(dev, nbytes)
-    check(lib().ss_mit_attn_bwd(dt(q), _p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(dq), _p(dkv), B, N, Nk, heads, D, float(D) ** -0.5,
-                                _p(ws), ws.numel(), _stream()))
+    check(lib().ss_mit_attn_bwd(dt(q), _p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(dq), _p(dkv), B, N, Nk, heads, D,
+                                float(D) ** -0.5 if scale is None else float(scale), _p(ws), ws.numel(), _stream()))
     return dq, dkv
 
 
@@ -1535,6 +1535,111 @@ def image_affine(x, M, c, out_dtype=torch.float32, pre_act=0):
     code = {torch.float32: 0, torch.bfloat16: 1}[out_dtype]
     check(lib().ss_image_affine(code, _p(x), ldi, _p(M), _p(c), _p(out), mrows, rows // images, images, cin, mrows, pre_act, _stream()))
     return out
+
+
+# ---------------------------------------------------------------------------------- TopFormer training (backward-side kernels)
+def dwconvk_dgrad(g, wkkc, B, H, W, k, stride, pad_top, pad_left, Ho, Wo):
+    """g [B*Ho*Wo, C] -> dx [B*H*W, C]: data gradient of dwconvk_fwd (wkkc: the forward's tap-major [k*k, C] fp32 weight)."""
+    dev = _dev(g)
+    rows, C, ld = _mat(g, 'g')
+    if ld != C or rows != B * Ho * Wo:
+        raise ValueError('dwconvk_dgrad: g must be dense [B*Ho*Wo, C]')
+    _f32(wkkc, 'wkkc', k * k * C)
+    dx = torch.empty((B * H * W, C), dtype=g.dtype, device=dev)
+    check(lib().ss_dwconvk_dgrad(dt(g), _p(g), _p(wkkc), _p(dx), B, H, W, C, k, stride, pad_top, pad_left, Ho, Wo, _stream()))
+    return dx
+
+
+def dwconvk_wgrad_s(g, x, B, H, W, k, stride, pad_top, pad_left, Ho, Wo):
+    """-> dw_db [(k*k + 1), C] fp32 (taps tap-major, then the bias gradient) for stride 1 / 2 and asymmetric padding; k in {3, 5}."""
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    rg, Cg, ldg = _mat(g, 'g')
+    if ld != C or rows != B * H * W or ldg != C or Cg != C or rg != B * Ho * Wo or g.dtype != x.dtype:
+        raise ValueError('dwconvk_wgrad_s: bad x / g')
+    out = torch.empty((k * k + 1, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, 256 * (k * k + 1) * C * 4)
+    check(lib().ss_dwconvk_wgrad_s(dt(x), _p(g), _p(x), _p(out), B, H, W, C, k, stride, pad_top, pad_left, Ho, Wo, _p(ws), ws.numel(), _stream()))
+    return out
+
+
+def avgpool_bwd(g, B, H, W, win):
+    """g [B*(H/win)*(W/win), C] (may be a channel slice) -> dx [B*H*W, C]."""
+    dev = _dev(g)
+    rows, C, ldg = _mat(g, 'g')
+    if rows != B * (H // win) * (W // win):
+        raise ValueError('avgpool_bwd: bad g')
+    dx = torch.empty((B * H * W, C), dtype=g.dtype, device=dev)
+    check(lib().ss_avgpool_bwd(dt(g), _p(g), ldg, _p(dx), C, B, H, W, C, win, _stream()))
+    return dx
+
+
+def act_bwd(dy, y, code):
+    """dx = dy * act'(.) from the activation's output y (2 ReLU, 3 ReLU6, 5 sigmoid)."""
+    _dev(dy)
+    if dy.shape != y.shape or dy.dtype != y.dtype or not dy.is_contiguous() or not y.is_contiguous():
+        raise ValueError('act_bwd: dy / y must be alike and contiguous')
+    dx = torch.empty_like(dy)
+    check(lib().ss_act_bwd(dt(dy), _p(dy), _p(y), _p(dx), dy.numel(), code, _stream()))
+    return dx
+
+
+def mul(a, b):
+    _dev(a)
+    if a.shape != b.shape or a.dtype != b.dtype or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError('mul: operands must be alike and contiguous')
+    out = torch.empty_like(a)
+    check(lib().ss_mul(dt(a), _p(a), _p(b), _p(out), a.numel(), _stream()))
+    return out
+
+
+def simam_bwd(dy, x, moments, k, images, dk, accumulate_dk=True):
+    """-> dx (like x); dk (one fp32) is written or accumulated in place."""
+    dev = _dev(x)
+    rows, C, ldx = _mat(x, 'x')
+    rd, Cd, ldd = _mat(dy, 'dy')
+    if (rd, Cd) != (rows, C) or dy.dtype != x.dtype or rows % images:
+        raise ValueError('simam_bwd: bad shapes')
+    _f32(moments, 'moments', images * 2 * C), _f32(k, 'k', 1), _f32(dk, 'dk', 1)
+    dx = torch.empty((rows, C), dtype=x.dtype, device=dev)
+    sums = torch.empty((images, 2, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, images * COLRED_BLOCKS * 2 * C * 4)
+    check(lib().ss_simam_bwd(dt(x), _p(dy), ldd, _p(x), ldx, _p(moments), _p(k), _p(dx), C, _p(dk), int(accumulate_dk), _p(sums), rows // images, C, images,
+                             _p(ws), ws.numel(), _stream()))
+    return dx
+
+
+def groupnorm_fwd(x, images, groups, cg, pitch, eps, gamma, beta, pre_act=0):
+    """fp32 x [images*n, ncol] -> (y, stats [images, groups, 2]); column g*pitch + j (j < cg) is channel g*cg + j, the rest padding."""
+    dev = _dev(x)
+    rows, ncol, ldx = _mat(x, 'x')
+    if x.dtype != torch.float32 or rows % images:
+        raise ValueError('groupnorm_fwd: x must be fp32 [images*n, ncol]')
+    _f32(gamma, 'gamma', groups * cg), _f32(beta, 'beta', groups * cg)
+    mom = image_moments(x, images, pre_act=pre_act)
+    coef = torch.empty((images, 2, ncol), dtype=torch.float32, device=dev)
+    stats = torch.empty((images, groups, 2), dtype=torch.float32, device=dev)
+    y = torch.empty((rows, ncol), dtype=torch.float32, device=dev)
+    check(lib().ss_groupnorm_fwd(_p(x), ldx, _p(mom), rows // images, images, groups, cg, pitch, ncol, eps, _p(gamma), _p(beta), pre_act, _p(coef), _p(stats),
+                                 _p(y), ncol, _stream()))
+    return y, stats
+
+
+def groupnorm_bwd(dy, x, stats, gamma, images, groups, cg, pitch, pre_act=0):
+    """-> dx [like x], dgb [2, groups*cg] fp32 (dgamma, dbeta)."""
+    dev = _dev(x)
+    rows, ncol, ldx = _mat(x, 'x')
+    rd, nd, ldd = _mat(dy, 'dy')
+    if x.dtype != torch.float32 or dy.dtype != torch.float32 or (rd, nd) != (rows, ncol) or rows % images:
+        raise ValueError('groupnorm_bwd: bad shapes')
+    _f32(stats, 'stats', images * groups * 2), _f32(gamma, 'gamma', groups * cg)
+    dx = torch.empty((rows, ncol), dtype=torch.float32, device=dev)
+    dgb = torch.empty((2, groups * cg), dtype=torch.float32, device=dev)
+    scratch = torch.empty(images * 5 * ncol, dtype=torch.float32, device=dev)
+    ws = workspace(dev, images * COLRED_BLOCKS * 2 * ncol * 4)
+    check(lib().ss_groupnorm_bwd(_p(dy), ldd, _p(x), ldx, _p(stats), _p(gamma), rows // images, images, groups, cg, pitch, ncol, pre_act, _p(dx), ncol,
+                                 _p(dgb), _p(scratch), _p(ws), ws.numel(), _stream()))
+    return dx, dgb
 
 
 # ---------------------------------------------------------------------------------- gradient delivery (engine.FlatParams)

@@ -18,7 +18,8 @@ flat launch sequence over channels-last token matrices:
 
 Instantiated quirks kept: injection ``global_act`` uses the backbone activation (ReLU6), the attention
 projection is act -> conv -> BN, the pyramid uses ReLU.  Unlike the reference, construction works more than once per process.
-Training mode (batch-statistic BatchNorm + backward) and the RefinerHead are not on the MI355X path yet: they raise.
+In train mode ``TopFormerModel.forward`` runs topformer_train.py (batch-statistic BatchNorm, running-statistic updates and the backward
+to every parameter: what train.py:45-52 needs); this file is the eval-mode path with BatchNorm folded into the weights.
 """
 import os
 from collections import OrderedDict
@@ -366,7 +367,8 @@ class TopFormerBackBone(nn.Module):
 
     def _plan_for(self, model, x):
         if self.training:
-            raise NotImplementedError('TopFormer on the MI355X path is inference-only (call .eval()); training-mode BatchNorm is not built yet')
+            raise NotImplementedError('the folded-BatchNorm plan is for eval mode; in train mode call TopFormerModel.forward (topformer_train.py) -- '
+                                      'the backbone alone has no training path')
         key = (compute_dtype_for(x), model.head is not None, x.device)
         fp = self._fingerprint(model)
         hit = self._plans.get(key)
@@ -478,6 +480,9 @@ class TopFormerModel(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         b, c, H, W = x.shape
+        if self.training:                                                   # batch-statistic BatchNorm + a backward: topformer_train.py
+            from .topformer_train import train_forward
+            return train_forward(self, x)
         with torch.no_grad():
             logits4, h4, w4 = self._logits4(x)
             full = ops.bilinear_fwd(logits4, b, h4, w4, H, W)
