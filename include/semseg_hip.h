@@ -91,7 +91,7 @@ int ss_sum_slices(int dtype, const void* x, int64_t ld, int nslices, int slice_s
 /* ---- nn.BatchNorm2d (+ nn.Mish) of modules/lawin.py:54,101-105 on channels-last rows.
  * stats = [2,C] fp32 (mean, rstd).  ss_bn_stats also updates running_mean/var (unbiased) and num_batches_tracked like
  * torch (pass NULLs to skip).  ss_bn_apply: y = res + mask[row/rows_per_image, c] * act(gamma*(z-mean)*rstd + beta),
- * act: 0 none, 1 Mish; mask = the Dropout2d(0.1) multiplier of modules/lawin.py:138,228 (NULL = none). */
+ * act: 0 none, 1 Mish, 2 ReLU, 3 ReLU6 (the conv-BN-act units of modules/topformer.py in train mode); mask = the Dropout2d(0.1) multiplier of modules/lawin.py:138,228 (NULL = none). */
 int ss_bn_stats(int dtype, const void* x, int64_t ld, int64_t rows, int C, float eps, float momentum, float* stats,
                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float* workspace,
                 int64_t ws_bytes, hipStream_t stream);
@@ -480,7 +480,7 @@ int ss_inject_fuse_sum(int dtype, const void* local, int64_t ldl, const void* ga
  * ss_dwconvk_dgrad: data gradient of ss_dwconvk_fwd for stride 1 / 2 and the asymmetric AutoPadding (modules/layers.py:146-164;
  *   InvertedResidual conv_dw, modules/topformer.py:166-184): g [B*Ho*Wo][C] -> dx [B*H*W][C]; wkkc as the forward's.  C % 8 == 0.
  * ss_dwconvk_wgrad_s: the weight / bias gradient for the same geometry, dw_db = [(k*k + 1)][C] fp32 (taps tap-major, then the bias
- *   gradient); k in {3, 5}; workspace >= 256 * (k*k+1) * C floats.
+ *   gradient); k in {3, 5}, C % 8 == 0; workspace >= 512 * (k*k+1) * C floats.
  * ss_avgpool_bwd: gradient of ss_avgpool (PyramidPoolAgg, modules/topformer.py:527-552); g may be a channel slice (row pitch ldg).
  * ss_act_bwd: dx = dy * act'(.) from the activation's OUTPUT y (2 ReLU, 3 ReLU6 -- open interval like torch's hardtanh backward --,
  *   5 sigmoid, 0 copy).  ss_mul: out = a * b (InjectionDotSum's product, modules/topformer.py:640-673, and its two gradients). */

@@ -458,7 +458,7 @@ __device__ __forceinline__ int64_t bn_image_of(int64_t row, int64_t rows_per_ima
 }
 static inline int pow2_shift(int64_t v) { return (v > 0 && (v & (v - 1)) == 0) ? __builtin_ctzll((unsigned long long)v) : -1; }
 
-// y[r] = res[r] + mask[b,c] * act(gamma * (z - mean) * rstd + beta);   act: 0 none, 1 Mish
+// y[r] = res[r] + mask[b,c] * act(gamma * (z - mean) * rstd + beta);   act: 0 none, 1 Mish, 2 ReLU, 3 ReLU6 (the last two: ss_bn_apply / ss_bn_bwd only)
 // UP: z is the coarse map and `up` its resize geometry (rows = B*ho*wo virtual rows, see UpGeom)
 template <typename T, int ACT, bool MASK, bool RES, bool UP = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, int64_t ldz, const float* __restrict__ stats,
@@ -496,6 +496,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
                     for (int e = 0; e < 8; ++e) {
                         float u = fmaf(UP ? up_value<T>(ut[UP ? j : 0], e) : v[j].get(e), sc.v[e], sh.v[e]);
                         if (ACT == 1) u = mish_f(u);
+                        if (ACT == 2) u = fmaxf(u, 0.f);
+                        if (ACT == 3) u = fminf(fmaxf(u, 0.f), 6.f);
                         if (MASK) u *= m[j].v[e];
                         if (RES) u += q[j].get(e);
                         o.v[e] = u;
@@ -518,18 +520,18 @@ extern "C" int ss_bn_apply(int dtype, const void* z, int64_t ldz, const float* s
     SS_CHECK(z && stats && gamma && beta && y && rows > 0 && C > 0 && C % 8 == 0, "ss_bn_apply: bad arguments (C=%d)", C);
     SS_CHECK(ldz >= C && ldy >= C && ldz % 8 == 0 && ldy % 8 == 0 && (!res || (ldr >= C && ldr % 8 == 0)), "ss_bn_apply: bad leading dimensions");
     SS_CHECK(!mask || rows_per_image > 0, "ss_bn_apply: rows_per_image required with a mask");
-    SS_CHECK(act == 0 || act == 1, "ss_bn_apply: act must be 0 (none) or 1 (Mish)");
+    SS_CHECK(act >= 0 && act <= 3, "ss_bn_apply: act must be 0 (none), 1 (Mish), 2 (ReLU) or 3 (ReLU6)");
     ColGeom g = col_geom(rows, C);
     BnWalk w{g.cpb, g.rpb};
     const int blocks = bn_walk_blocks(rows, g.rpb), sh = pow2_shift(rows_per_image);
 #define SS_BN_APPLY(ACT, MASK, RES) hipLaunchKernelGGL((bn_apply_kernel<T, ACT, MASK, RES>), dim3(blocks), dim3(256), 0, stream, (const T*)z, ldz, \
         stats, gamma, beta, (const T*)res, ldr, mask, rows_per_image, sh, (T*)y, ldy, rows, C, w, UpGeom{})
+#define SS_BN_APPLY_ACT(ACT) do { if (mask) { if (res) SS_BN_APPLY(ACT, true, true); else SS_BN_APPLY(ACT, true, false); } \
+                                  else { if (res) SS_BN_APPLY(ACT, false, true); else SS_BN_APPLY(ACT, false, false); } } while (0)
     SS_DISPATCH(dtype, {
-        if (act) { if (mask) { if (res) SS_BN_APPLY(1, true, true); else SS_BN_APPLY(1, true, false); }
-                   else { if (res) SS_BN_APPLY(1, false, true); else SS_BN_APPLY(1, false, false); } }
-        else { if (mask) { if (res) SS_BN_APPLY(0, true, true); else SS_BN_APPLY(0, true, false); }
-               else { if (res) SS_BN_APPLY(0, false, true); else SS_BN_APPLY(0, false, false); } }
+        if (act == 1) SS_BN_APPLY_ACT(1); else if (act == 2) SS_BN_APPLY_ACT(2); else if (act == 3) SS_BN_APPLY_ACT(3); else SS_BN_APPLY_ACT(0);
     });
+#undef SS_BN_APPLY_ACT
 #undef SS_BN_APPLY
     SS_LAUNCH_CHECK();
     return 0;
@@ -613,6 +615,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const T* __restrict__ dy, i
                             float gg = d[j].get(e);
                             if (MASK) gg *= m[j].v[e];
                             if (ACT == 1) gg *= mish_grad(fmaf(xh, gm.v[e], bt.v[e]));
+                            if (ACT == 2) gg = fmaf(xh, gm.v[e], bt.v[e]) > 0.f ? gg : 0.f;
+                            if (ACT == 3) { const float u = fmaf(xh, gm.v[e], bt.v[e]); gg = (u > 0.f && u < 6.f) ? gg : 0.f; }
                             if (PASS2) o.v[e] = fmaf(k0.v[e], gg, fmaf(xh, k2.v[e], k1.v[e]));
                             else { acc[0][e] += gg; acc[1][e] = fmaf(gg, xh, acc[1][e]); }
                         }
@@ -670,7 +674,7 @@ extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, 
     SS_CHECK(dy && z && stats && gamma && beta && dz && dgamma_dbeta && workspace && rows > 0 && C > 0 && C % 8 == 0, "ss_bn_bwd: bad arguments");
     SS_CHECK(ldd >= C && ldz >= C && ldo >= C && ldd % 8 == 0 && ldz % 8 == 0 && ldo % 8 == 0, "ss_bn_bwd: bad leading dimensions");
     SS_CHECK(!mask || rows_per_image > 0, "ss_bn_bwd: rows_per_image required with a mask");
-    SS_CHECK(act == 0 || act == 1, "ss_bn_bwd: act must be 0 (none) or 1 (Mish)");
+    SS_CHECK(act >= 0 && act <= 3, "ss_bn_bwd: act must be 0 (none), 1 (Mish), 2 (ReLU) or 3 (ReLU6)");
     ColGeom g = col_geom(rows, C);
     SS_CHECK(ws_bytes >= ((int64_t)g.nb * 2 * C + 2 * C) * 4, "ss_bn_bwd: workspace too small");
     float* coef = workspace + (int64_t)g.nb * 2 * C;
@@ -678,9 +682,10 @@ extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, 
     const int blocks2 = bn_walk_blocks(rows, g.rpb), sh = pow2_shift(rows_per_image);
 #define SS_BN_BWD(ACT, MASK, P2, GRID) hipLaunchKernelGGL((bn_bwd_kernel<T, ACT, MASK, P2>), dim3(GRID), dim3(256), 0, stream, (const T*)dy, ldd, \
         (const T*)z, ldz, stats, gamma, beta, mask, rows_per_image, sh, coef, (T*)dz, ldo, workspace, rows, C, w, UpGeom{})
+#define SS_BN_BWD_ACT(ACT, P2, GRID) do { if (mask) SS_BN_BWD(ACT, true, P2, GRID); else SS_BN_BWD(ACT, false, P2, GRID); } while (0)
 #define SS_BN_BWD_PASS(P2, GRID) do { \
-        if (act) { if (mask) SS_BN_BWD(1, true, P2, GRID); else SS_BN_BWD(1, false, P2, GRID); } \
-        else { if (mask) SS_BN_BWD(0, true, P2, GRID); else SS_BN_BWD(0, false, P2, GRID); } } while (0)
+        if (act == 1) SS_BN_BWD_ACT(1, P2, GRID); else if (act == 2) SS_BN_BWD_ACT(2, P2, GRID); \
+        else if (act == 3) SS_BN_BWD_ACT(3, P2, GRID); else SS_BN_BWD_ACT(0, P2, GRID); } while (0)
     SS_DISPATCH(dtype, {
         SS_BN_BWD_PASS(false, g.nb);
         SS_LAUNCH_CHECK();
@@ -689,6 +694,7 @@ extern "C" int ss_bn_bwd(int dtype, const void* dy, int64_t ldd, const void* z, 
         SS_BN_BWD_PASS(true, blocks2);
     });
 #undef SS_BN_BWD_PASS
+#undef SS_BN_BWD_ACT
 #undef SS_BN_BWD
     SS_LAUNCH_CHECK();
     return 0;

@@ -56,49 +56,76 @@ __global__ __launch_bounds__(256) void dwk_dgrad_kernel(const T* __restrict__ g,
 
 // ------------------------------------------------------------------ depthwise k x k, stride s: weight + bias gradient
 // dw[ky, kx, c] = sum_{b, oy, ox} g[b, oy, ox, c] * x[b, oy*s - pt + ky, ox*s - pl + kx, c];  db[c] = sum g.
-// A workgroup = 64 output-pixel lanes x 4 channel-pair lanes... kept simple: a thread owns 2 channels of one pixel lane and all k*k + 1
-// sums; the pixel lanes of a workgroup are combined through LDS in a fixed order; partial [nb][(k*k+1)][C], reduced by dwk_wgrad_final.
-template <typename T, int KK>
-__global__ __launch_bounds__(256) void dwk_wgrad_kernel(const T* __restrict__ g, const T* __restrict__ x, float* __restrict__ partial, int B, int H,
-                                                        int W, int C, int k, int s, int pt, int pl, int Ho, int Wo, int cpb) {
-    // cpb channel pairs per workgroup (power of two <= 256), 256 / cpb pixel lanes
-    __shared__ float sh[256 * 2];
-    const int tid = threadIdx.x, cl = tid % cpb, pl_ = tid / cpb, nlanes = 256 / cpb;
-    const int c = (blockIdx.y * cpb + cl) * 2;
-    const bool cok = c < C;
-    float acc[KK + 1][2];
+// A thread owns CH consecutive channels of one pixel lane and all K*K + 1 sums for them (CH = 8 for 3x3, 4 for 5x5: 80 / 104
+// accumulators); consecutive threads take consecutive channel chunks of one pixel, so a wave reads whole pixel rows; the pixel lanes of
+// a workgroup are combined through LDS in a fixed order; partial [nb][(K*K+1)][C], reduced by dwk_wgrad_final.
+template <typename T, int CH> __device__ __forceinline__ void load_n(const T* p, float (&v)[CH]);
+template <> __device__ __forceinline__ void load_n<float, 8>(const float* p, float (&v)[8]) { const F8 r = load8(p);
 #pragma unroll
-    for (int t = 0; t <= KK; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
+    for (int e = 0; e < 8; ++e) v[e] = r.v[e]; }
+template <> __device__ __forceinline__ void load_n<bf16, 8>(const bf16* p, float (&v)[8]) { const F8 r = load8(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = r.v[e]; }
+template <> __device__ __forceinline__ void load_n<float, 4>(const float* p, float (&v)[4]) { const floatx4 r = *(const floatx4*)p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = r[e]; }
+template <> __device__ __forceinline__ void load_n<bf16, 4>(const bf16* p, float (&v)[4]) { const bf16x4 r = *(const bf16x4*)p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)r[e]; }
+
+template <typename T, int K, int CH>
+__global__ __launch_bounds__(256) void dwk_wgrad_kernel(const T* __restrict__ g, const T* __restrict__ x, float* __restrict__ partial, int B, int H,
+                                                        int W, int C, int s, int pt, int pl, int Ho, int Wo, int cpb) {
+    constexpr int KK = K * K;
+    __shared__ float sh[256 * CH];
+    const int tid = threadIdx.x, cl = tid % cpb, lane = tid / cpb, nlanes = 256 / cpb;
+    const int c = (blockIdx.y * cpb + cl) * CH;
+    const bool cok = c < C;
+    float acc[KK + 1][CH];
+#pragma unroll
+    for (int t = 0; t <= KK; ++t)
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[t][e] = 0.f;
     const int64_t npix = (int64_t)B * Ho * Wo;
     if (cok) {
-        for (int64_t p = (int64_t)blockIdx.x * nlanes + pl_; p < npix; p += (int64_t)gridDim.x * nlanes) {
-            const int ox = (int)(p % Wo); int64_t q = p / Wo;
+        for (int64_t p = (int64_t)blockIdx.x * nlanes + lane; p < npix; p += (int64_t)gridDim.x * nlanes) {
+            const int ox = (int)(p % Wo); const int64_t q = p / Wo;
             const int oy = (int)(q % Ho);
             const int b = (int)(q / Ho);
-            const T* gp = g + p * C + c;
-            const float g0 = to_f(gp[0]), g1 = to_f(gp[1]);
-            acc[KK][0] += g0; acc[KK][1] += g1;
+            float gv[CH];
+            load_n<T, CH>(g + p * C + c, gv);
 #pragma unroll
-            for (int t = 0; t < KK; ++t) {
-                const int ky = t / k, kx = t - ky * k;        // k is uniform: the division is cheap next to the loads
-                const int iy = oy * s - pt + ky, ix = ox * s - pl + kx;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                    const T* xp = x + (((int64_t)b * H + iy) * W + ix) * C + c;
-                    acc[t][0] = fmaf(g0, to_f(xp[0]), acc[t][0]);
-                    acc[t][1] = fmaf(g1, to_f(xp[1]), acc[t][1]);
+            for (int e = 0; e < CH; ++e) acc[KK][e] += gv[e];
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const int iy = oy * s - pt + ky;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int ix = ox * s - pl + kx;
+                    if (ix < 0 || ix >= W) continue;
+                    float xv[CH];
+                    load_n<T, CH>(x + (((int64_t)b * H + iy) * W + ix) * C + c, xv);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) acc[ky * K + kx][e] = fmaf(gv[e], xv[e], acc[ky * K + kx][e]);
                 }
             }
         }
     }
+#pragma unroll
     for (int t = 0; t <= KK; ++t) {
         __syncthreads();
-        sh[tid * 2] = acc[t][0]; sh[tid * 2 + 1] = acc[t][1];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) sh[tid * CH + e] = acc[t][e];
         __syncthreads();
-        if (pl_ == 0 && cok) {
-            float s0 = 0.f, s1 = 0.f;
-            for (int j = 0; j < nlanes; ++j) { s0 += sh[(j * cpb + cl) * 2]; s1 += sh[(j * cpb + cl) * 2 + 1]; }
-            float* dst = partial + ((int64_t)blockIdx.x * (KK + 1) + t) * C + c;
-            dst[0] = s0; dst[1] = s1;
+        // CH * cpb sums of nlanes terms each: spread over the workgroup's threads (thread u sums column u)
+        for (int u = tid; u < cpb * CH; u += 256) {
+            const int ucl = u / CH, ue = u % CH, uc = (blockIdx.y * cpb + ucl) * CH + ue;
+            if (uc < C) {
+                float sum = 0.f;
+                for (int j = 0; j < nlanes; ++j) sum += sh[(j * cpb + ucl) * CH + ue];
+                partial[((int64_t)blockIdx.x * (KK + 1) + t) * C + uc] = sum;
+            }
         }
     }
 }
@@ -339,21 +366,25 @@ extern "C" int ss_dwconvk_dgrad(int dtype, const void* g, const float* wkkc, voi
     return 0;
 }
 
-// dw_db [(k*k + 1)][C] fp32 (taps tap-major, then the bias gradient) of y = dw_{k, stride, pads}(x); workspace >= 256 * (k*k+1) * C floats
+// dw_db [(k*k + 1)][C] fp32 (taps tap-major, then the bias gradient) of y = dw_{k, stride, pads}(x); workspace >= 512 * (k*k+1) * C floats
 extern "C" int ss_dwconvk_wgrad_s(int dtype, const void* g, const void* x, float* dw_db, int B, int H, int W, int C, int k, int stride,
                                   int pad_top, int pad_left, int Ho, int Wo, float* workspace, int64_t ws_bytes, hipStream_t stream) {
-    SS_CHECK(g && x && dw_db && workspace && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 2 == 0 && (k == 3 || k == 5) &&
-             (stride == 1 || stride == 2) && pad_top >= 0 && pad_left >= 0, "ss_dwconvk_wgrad_s: bad arguments (C=%d k=%d stride=%d; k must be 3 or 5)", C, k, stride);
-    int cpb = 1; while (cpb < C / 2 && cpb < 64) cpb <<= 1;
-    const int groups = (int)cdiv(C / 2, cpb), nlanes = 256 / cpb;
+    SS_CHECK(g && x && dw_db && workspace && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0 && (k == 3 || k == 5) &&
+             (stride == 1 || stride == 2) && pad_top >= 0 && pad_left >= 0 && aligned16(g) && aligned16(x),
+             "ss_dwconvk_wgrad_s: bad arguments (C=%d k=%d stride=%d; k must be 3 or 5, C a multiple of 8)", C, k, stride);
+    const int CH = k == 3 ? 8 : 4, chunks = C / CH;
+    int cpb = 1; while (cpb < chunks && cpb < 64) cpb <<= 1;
+    const int groups = (int)cdiv(chunks, cpb), nlanes = 256 / cpb;
     const int64_t npix = (int64_t)B * Ho * Wo;
-    int nb = (int)cdiv(npix, (int64_t)nlanes * 8); if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+    int nb = (int)cdiv(npix, (int64_t)nlanes * 4);
+    const int cap = groups >= 4 ? 256 : 512;
+    if (nb > cap) nb = cap; if (nb < 1) nb = 1;
     const int rows = k * k + 1;
     SS_CHECK(ws_bytes >= (int64_t)nb * rows * C * 4, "ss_dwconvk_wgrad_s: workspace too small");
     dim3 grid((unsigned)nb, (unsigned)groups);
-    if (k == 3) SS_DISPATCH(dtype, hipLaunchKernelGGL((dwk_wgrad_kernel<T, 9>), grid, dim3(256), 0, stream, (const T*)g, (const T*)x, workspace, B, H, W, C, k,
+    if (k == 3) SS_DISPATCH(dtype, hipLaunchKernelGGL((dwk_wgrad_kernel<T, 3, 8>), grid, dim3(256), 0, stream, (const T*)g, (const T*)x, workspace, B, H, W, C,
                                                       stride, pad_top, pad_left, Ho, Wo, cpb));
-    else SS_DISPATCH(dtype, hipLaunchKernelGGL((dwk_wgrad_kernel<T, 25>), grid, dim3(256), 0, stream, (const T*)g, (const T*)x, workspace, B, H, W, C, k,
+    else SS_DISPATCH(dtype, hipLaunchKernelGGL((dwk_wgrad_kernel<T, 5, 4>), grid, dim3(256), 0, stream, (const T*)g, (const T*)x, workspace, B, H, W, C,
                                                stride, pad_top, pad_left, Ho, Wo, cpb));
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(dwk_wgrad_final, dim3((unsigned)cdiv(rows * C, 256)), dim3(256), 0, stream, (const float*)workspace, nb, rows * C, dw_db);

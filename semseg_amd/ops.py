@@ -1558,7 +1558,7 @@ def dwconvk_wgrad_s(g, x, B, H, W, k, stride, pad_top, pad_left, Ho, Wo):
     if ld != C or rows != B * H * W or ldg != C or Cg != C or rg != B * Ho * Wo or g.dtype != x.dtype:
         raise ValueError('dwconvk_wgrad_s: bad x / g')
     out = torch.empty((k * k + 1, C), dtype=torch.float32, device=dev)
-    ws = workspace(dev, 256 * (k * k + 1) * C * 4)
+    ws = workspace(dev, 512 * (k * k + 1) * C * 4)
     check(lib().ss_dwconvk_wgrad_s(dt(x), _p(g), _p(x), _p(out), B, H, W, C, k, stride, pad_top, pad_left, Ho, Wo, _p(ws), ws.numel(), _stream()))
     return out
 

@@ -8,7 +8,8 @@ engine.FlatParams' flat buffer when the model is registered there); every FLOP i
 
 Layer by layer (reference file:line):
 * conv 1x1 + BatchNorm (+ ReLU / ReLU6) (modules/blocks.py:17-198 'CNA'): ss_gemm_nt -> ss_bn_stats (updates running_mean / running_var
-  / num_batches_tracked in place) -> ss_bn_apply (+ residual) -> ss_act; backward ss_act_bwd -> ss_bn_bwd -> ss_gemm_tn / ss_gemm_nt.
+  / num_batches_tracked in place) -> ss_bn_apply (activation and residual in the same pass); backward ss_bn_bwd (the activation mask from
+  the recomputed pre-activation) -> ss_gemm_tn / ss_gemm_nt.
 * depthwise k x k, stride 1 / 2, AutoPadding (modules/topformer.py:166-184, modules/layers.py:146-164): ss_dwconvk_fwd; backward
   ss_dwconvk_dgrad + ss_dwconvk_wgrad_s.
 * stem 3x3 / stride 2 (modules/topformer.py:1023-1033): ss_im2col_ex + GEMM (the weight gradient is one ss_gemm_tn on the patch matrix).
@@ -87,10 +88,10 @@ def _bn_args(bn):
     return bn.weight.detach(), bn.bias.detach(), float(bn.eps), float(bn.momentum)
 
 
-def _bn_fwd(z, bn, res=None, out=None):
+def _bn_fwd(z, bn, res=None, out=None, act=0):
     gamma, beta, eps, mom = _bn_args(bn)
     stats = ops.bn_stats(z, eps, mom, bn.running_mean, bn.running_var, bn.num_batches_tracked)
-    return ops.bn_apply(z, stats, gamma, beta, res=res, out=out), stats
+    return ops.bn_apply(z, stats, gamma, beta, act=act, res=res, out=out), stats
 
 
 def conv_bn(tape, x, unit, res=None, need_dx=True, defer_dx=False):
@@ -102,16 +103,14 @@ def conv_bn(tape, x, unit, res=None, need_dx=True, defer_dx=False):
     O = conv.weight.shape[0]
     w2 = conv.weight.detach().reshape(O, -1)
     z = ops.gemm_nt(x.t, tape.wmat(w2))
-    y, stats = _bn_fwd(z, bn, res=res.t if res is not None else None)
-    out = _V(ops.act(y, unit.act) if unit.act else y)
+    y, stats = _bn_fwd(z, bn, res=res.t if res is not None else None, act=unit.act)      # ReLU / ReLU6 inside the normalisation pass
+    out = _V(y)
 
     def bwd():
         g = out.g
         if res is not None:
             tape.acc(res, g)
-        if unit.act:
-            g = ops.act_bwd(g, out.t, unit.act)
-        dz, dgb = ops.bn_bwd(g, z, stats, bn.weight.detach(), bn.bias.detach())
+        dz, dgb = ops.bn_bwd(g, z, stats, bn.weight.detach(), bn.bias.detach(), act=unit.act)      # mask from the recomputed pre-activation
         tape.pg(bn.weight, dgb[0]), tape.pg(bn.bias, dgb[1])
         tape.pg(conv.weight, ops.gemm_tn(dz, x.t))
         if defer_dx:
@@ -131,12 +130,11 @@ def dw_bn(tape, x, unit, B, H, W):
     p0, _ = auto_pad(k, s)
     Ho, Wo = H // s, W // s
     z = ops.dwconvk_fwd(x.t, wkkc, bias, B, H, W, k, s, p0, p0, Ho, Wo, act=0)
-    y, stats = _bn_fwd(z, bn)
-    out = _V(ops.act(y, unit.act) if unit.act else y)
+    y, stats = _bn_fwd(z, bn, act=unit.act)
+    out = _V(y)
 
     def bwd():
-        g = ops.act_bwd(out.g, out.t, unit.act) if unit.act else out.g
-        dz, dgb = ops.bn_bwd(g, z, stats, bn.weight.detach(), bn.bias.detach())
+        dz, dgb = ops.bn_bwd(out.g, z, stats, bn.weight.detach(), bn.bias.detach(), act=unit.act)
         tape.pg(bn.weight, dgb[0]), tape.pg(bn.bias, dgb[1])
         dwdb = ops.dwconvk_wgrad_s(dz, x.t, B, H, W, k, s, p0, p0, Ho, Wo)
         tape.pg(conv.weight, ops.transpose_cast(dwdb[:k * k], F32))
@@ -157,12 +155,11 @@ def stem(tape, x, unit):
     col = ops.im2col_ex(t, B, H, W, cin, 3, 2, pt, pt, h, w)
     wp, _ = ops.pack_conv_weight(conv.weight.detach().float().contiguous(), tape.T, transposed=False)
     z = ops.gemm_nt(col, wp)
-    y, stats = _bn_fwd(z, bn)
-    out = _V(ops.act(y, unit.act))
+    y, stats = _bn_fwd(z, bn, act=unit.act)
+    out = _V(y)
 
     def bwd():
-        g = ops.act_bwd(out.g, out.t, unit.act)
-        dz, dgb = ops.bn_bwd(g, z, stats, bn.weight.detach(), bn.bias.detach())
+        dz, dgb = ops.bn_bwd(out.g, z, stats, bn.weight.detach(), bn.bias.detach(), act=unit.act)
         tape.pg(bn.weight, dgb[0]), tape.pg(bn.bias, dgb[1])
         tape.pg(conv.weight, ops.unpack_conv_wgrad(ops.gemm_tn(dz, col).contiguous(), conv.weight.shape[0], cin, 3))
     tape.push(bwd)
