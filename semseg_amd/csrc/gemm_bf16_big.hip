@@ -25,6 +25,73 @@ __device__ __forceinline__ int big_slot(int row, int chunk) {
     return R * 16 + ((((row & 1) << 3) | chunk) ^ (R & 15));
 }
 
+// ---- epilogue of a 256 x 256 tile through an LDS [m][n] image (pitch 528 bytes); all 512 threads, the operand stages are dead
+__device__ __forceinline__ void big_nt_epilogue(floatx16 (&acc)[2][4], const FastGemm& p, char* smem, int64_t m0, int n0, int tid, int wave, int wm, int wn,
+                                                int li, int lh) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int EP = BN * 2 + 16;
+    // ---- epilogue through an LDS [m][n] image (pitch EP bytes)
+    bf16* C = (bf16*)p.C;
+    constexpr int CPR = BN / 8;                        // 16-byte chunks per tile row
+    constexpr int RPP = 512 / CPR;                     // rows per pass
+    const int erow = tid / CPR, ech = tid % CPR;
+    const bool ncol_ok = n0 + ech * 8 < p.N;
+    if (p.res) {
+#pragma unroll 4
+        for (int ps = 0; ps < BM / RPP; ++ps) {
+            int row = ps * RPP + erow;
+            if (m0 + row < p.M && ncol_ok)
+                *(bf16x8*)(smem + row * EP + ech * 16) = *(const bf16x8*)(p.res + (m0 + row) * p.ldr + n0 + ech * 8);
+        }
+        __syncthreads();
+    }
+    nt_epilogue_dispatch<2, 4>(acc, p, smem, EP, m0, n0, wm * 64, wn * 128, li, lh);
+    __syncthreads();
+    if (p.w2) {
+        // second product: the finished bf16 tile [256 rows][256 = all N columns] times w2^T; wave w takes rows 32w .. 32w+31, the lane is
+        // a row again and its first register quads are the n2 <= 32 output columns.  The tile itself is not stored.
+        const int row = wave * 32 + li;
+        const bf16* wp = p.w2 + (int64_t)(li < p.n2 ? li : 0) * p.ldw2 + lh * 8;
+        const char* tp = smem + row * EP + lh * 16;
+        const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        floatx16 a2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+#pragma unroll 4
+        for (int ks = 0; ks < BN / 16; ++ks)
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(li < p.n2 ? *(const bf16x8*)(wp + ks * 16) : zero, *(const bf16x8*)(tp + ks * 32), a2, 0, 0, 0);
+        if (m0 + row < p.M) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 8 * g + 4 * lh;
+                if (c0 < p.n2) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)a2[4 * g + e];
+                    *(bf16x4*)(p.out2 + (m0 + row) * p.ldo2 + c0) = o;
+                }
+            }
+        }
+        return;
+    }
+    float sx[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sx[e] = 0.f; sq[e] = 0.f; }
+#pragma unroll 4
+    for (int ps = 0; ps < BM / RPP; ++ps) {
+        int row = ps * RPP + erow;
+        if (m0 + row < p.M && ncol_ok && (!(p.dbg & 1) || acc[0][0][0] == 12345.f)) {
+            const bf16x8 v = *(const bf16x8*)(smem + row * EP + ech * 16);
+            nt_store_chunk(p, C, m0 + row, n0 + ech * 8, v);
+            if (p.stat_ws) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; sx[e] += f; sq[e] = fmaf(f, f, sq[e]); }
+            }
+        }
+    }
+    if (p.stat_ws) nt_tile_stats<BN, RPP, 512>(p, smem, sx, sq, erow, ech, m0 / BM, n0, tid);
+}
+
 __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(FastGemm p) {
     constexpr int BM = 256, BN = 256, BK = 64;
     constexpr int IMG = BM * BK * 2;                  // one operand image: 32 KiB
@@ -94,67 +161,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(FastGemm p) {
         }
     }
     __syncthreads();
-
-    // ---- epilogue through an LDS [m][n] image (pitch EP bytes)
-    bf16* C = (bf16*)p.C;
-    constexpr int CPR = BN / 8;                        // 16-byte chunks per tile row
-    constexpr int RPP = 512 / CPR;                     // rows per pass
-    const int erow = tid / CPR, ech = tid % CPR;
-    const bool ncol_ok = n0 + ech * 8 < p.N;
-    if (p.res) {
-#pragma unroll 4
-        for (int ps = 0; ps < BM / RPP; ++ps) {
-            int row = ps * RPP + erow;
-            if (m0 + row < p.M && ncol_ok)
-                *(bf16x8*)(smem + row * EP + ech * 16) = *(const bf16x8*)(p.res + (m0 + row) * p.ldr + n0 + ech * 8);
-        }
-        __syncthreads();
-    }
-    nt_epilogue_dispatch<2, 4>(acc, p, smem, EP, m0, n0, wm * 64, wn * 128, li, lh);
-    __syncthreads();
-    if (p.w2) {
-        // second product: the finished bf16 tile [256 rows][256 = all N columns] times w2^T; wave w takes rows 32w .. 32w+31, the lane is
-        // a row again and its first register quads are the n2 <= 32 output columns.  The tile itself is not stored.
-        const int row = wave * 32 + li;
-        const bf16* wp = p.w2 + (int64_t)(li < p.n2 ? li : 0) * p.ldw2 + lh * 8;
-        const char* tp = smem + row * EP + lh * 16;
-        const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-        floatx16 a2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a2[r] = 0.f;
-#pragma unroll 4
-        for (int ks = 0; ks < BN / 16; ++ks)
-            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(li < p.n2 ? *(const bf16x8*)(wp + ks * 16) : zero, *(const bf16x8*)(tp + ks * 32), a2, 0, 0, 0);
-        if (m0 + row < p.M) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = 8 * g + 4 * lh;
-                if (c0 < p.n2) {
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)a2[4 * g + e];
-                    *(bf16x4*)(p.out2 + (m0 + row) * p.ldo2 + c0) = o;
-                }
-            }
-        }
-        return;
-    }
-    float sx[8], sq[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sx[e] = 0.f; sq[e] = 0.f; }
-#pragma unroll 4
-    for (int ps = 0; ps < BM / RPP; ++ps) {
-        int row = ps * RPP + erow;
-        if (m0 + row < p.M && ncol_ok && (!(p.dbg & 1) || acc[0][0][0] == 12345.f)) {
-            const bf16x8 v = *(const bf16x8*)(smem + row * EP + ech * 16);
-            nt_store_chunk(p, C, m0 + row, n0 + ech * 8, v);
-            if (p.stat_ws) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; sx[e] += f; sq[e] = fmaf(f, f, sq[e]); }
-            }
-        }
-    }
-    if (p.stat_ws) nt_tile_stats<BN, RPP, 512>(p, smem, sx, sq, erow, ech, m0 / BM, n0, tid);
+    big_nt_epilogue(acc, p, smem, m0, n0, tid, wave, wm, wn, li, lh);
 }
 
 // Wide form for outputs whose width is a multiple of 320 but not of 256 (the N = 320 projections of MiT stage 3): 256 x 320 tiles, the
@@ -328,6 +335,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256p_kernel(FastGemm p, int 
         if (pf_kt + 1 < nk) ++pf_kt;
         else if (pf_t + S < cnt) { pf_t += S; pf_kt = 0; pf_settile(pf_t); }
     };
+    // (tried: starting the workgroups of an XCD 0 .. 7 x 3.4 us out of phase, so that drains and k-loops of different CUs interleave
+    // instead of all draining at once -- no gain beyond the start delay itself on any shape: lockstep is not what the tile overhead is)
     pf_settile(s);
     for (int d = 0; d < pfd; ++d) { pf_advance(); prefetch(); }
     setptr(start + s);
@@ -373,6 +382,90 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256p_kernel(FastGemm p, int 
     }
 }
 
+// Deeper activation pipeline: the loop above keeps ONE k-tile in flight, and the activation operand streams from HBM (every A k-tile is new
+// data, ~2 us away under load) while a k-tile is multiplied in ~1.3 us: the k-iteration was the round trip, fills, products and stores
+// simply added up (tools/bench_gemm_parts.py: 262144 x 512 x 512 = 44 us of launch + first fill + drain, 55 us of fills, 83 us of
+// products, 29 us of stores, 198 us in total).  Here the A operand has THREE 32 KiB stages (two k-tiles in flight: 64 KiB per CU, 16 MB
+// chip-wide, what 8 TB/s x 2 us needs) and the weight operand, which comes from L2, keeps two: 5 x 32 KiB = all 160 KiB of LDS.
+// Fills are issued by hand (asm, so the compiler adds no waits of its own) with counted waits: at the top of iteration kt only the four
+// newest fills of each wave -- A(kt+1) -- may still be in flight.
+__global__ __launch_bounds__(512) void gemm_nt_bf16_256a_kernel(FastGemm p) {
+    constexpr int BK = 64;
+    constexpr int IMG = 256 * BK * 2;
+    constexpr int SMEM = 5 * IMG;                      // A0 A1 A2 B0 B1; the epilogue image (256 x 528 bytes) reuses it
+    static_assert(256 * (256 * 2 + 16) <= SMEM, "epilogue image must fit");
+    __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int wg = xcd_remap_big(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(wg / p.ntn) * 256;
+    const int n0 = (wg % p.ntn) * 256;
+    const int nk = (int)(p.K / BK);
+
+    const bf16* pa[4]; const bf16* pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int R = (wave * 4 + i) * 4 + (lane >> 4);
+        const int x = (lane & 15) ^ (R & 15);
+        const int row = 2 * R + (x >> 3), chunk = x & 7;
+        int64_t ra = m0 + row; if (ra >= p.M) ra = p.M - 1;
+        int rb = n0 + row; if (rb >= p.N) rb = p.N - 1;
+        pa[i] = p.A + ra * p.lda + chunk * 8;
+        pb[i] = p.B + (int64_t)rb * p.ldb + chunk * 8;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 4096);
+    auto issue_a = [&](int kt, int sa) {
+        const unsigned st = lds0 + sa * IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_b128(pa[i] + kt * BK, st + i * 1024);
+    };
+    auto issue_b = [&](int kt) {
+        const unsigned st = lds0 + (3 + (kt & 1)) * IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_b128(pb[i] + kt * BK, st + i * 1024);
+    };
+
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    issue_a(0, 0); issue_b(0);
+    if (nk > 1) issue_a(1, 1);
+    int sa = 0;                                        // A stage of k-tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+        // A(kt) and B(kt) have landed (fills complete in order; A(kt+1), the wave's four newest, may still be on its way), and
+        // nobody still reads the stages about to be refilled.  A bare s_barrier: __syncthreads() would wait for vmcnt(0)
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 1 < nk) issue_b(kt + 1);
+        if (kt + 2 < nk) issue_a(kt + 2, sa == 0 ? 2 : sa - 1);          // (kt + 2) % 3
+        const bf16* As = (const bf16*)(smem + sa * IMG);
+        const bf16* Bs = (const bf16*)(smem + (3 + (kt & 1)) * IMG);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 fa[2], fb[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[a] = *(const bf16x8*)(As + big_slot(wm * 64 + a * 32 + li, ks * 2 + lh) * 8);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[b] = *(const bf16x8*)(Bs + big_slot(wn * 128 + b * 32 + li, ks * 2 + lh) * 8);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
+        }
+        sa = sa == 2 ? 0 : sa + 1;
+    }
+    __syncthreads();
+    big_nt_epilogue(acc, p, smem, m0, n0, tid, wave, wm, wn, li, lh);
+}
+
 static int cu_count() {
     static int n = 0;
     if (!n) {
@@ -400,8 +493,11 @@ int ss_big_nt2_launch(FastGemm p, hipStream_t st) {
 }
 
 int ss_big_nt_launch(FastGemm p, hipStream_t st) {
-    static int mode = -1;                                  // SS_GEMM_BIG: 1 = one tile per workgroup, anything else = persistent
-    if (mode < 0) { const char* e = getenv("SS_GEMM_BIG"); mode = e && e[0] == '1' ? 1 : 2; }
+    // SS_GEMM_BIG: 1 = one tile per workgroup with two stages, 2 = persistent, default 3 = one tile per workgroup with the deep A pipeline.
+    // Whole training step on one box, back to back: 58.0 ms persistent, 57.6 ms two stages, 57.5 ms deep pipeline (tools/bench_gemm_modes.py
+    // has the shapes in isolation: the persistent form loses 5 - 10 % there on N >= 512, K = 512)
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("SS_GEMM_BIG"); mode = e && e[0] == '1' ? 1 : (e && e[0] == '2' ? 2 : 3); }
     { const char* e = getenv("SS_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.ntn = p.N / 256;
     const int ntiles = (int)(p.ntn * cdiv(p.M, 256));
@@ -411,6 +507,11 @@ int ss_big_nt_launch(FastGemm p, hipStream_t st) {
         static int pfd = -1;                               // prefetch distance in k-tiles (SS_GEMM_PFD; measured: 0 .. 5 all within 1 %)
         if (pfd < 0) { const char* e = getenv("SS_GEMM_PFD"); pfd = e ? atoi(e) : 2; if (pfd < 0 || pfd > 16) pfd = 2; }
         hipLaunchKernelGGL(gemm_nt_bf16_256p_kernel, dim3((unsigned)cu_count()), dim3(512), 0, st, p, ntiles, pfd);
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
+    if (mode == 3 && p.K >= 192) {
+        hipLaunchKernelGGL(gemm_nt_bf16_256a_kernel, dim3((unsigned)(p.ntn * cdiv(p.M, 256))), dim3(512), 0, st, p);
         SS_LAUNCH_CHECK();
         return 0;
     }
