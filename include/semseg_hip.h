@@ -491,6 +491,14 @@ int ss_dwconvk_wgrad_s(int dtype, const void* g, const void* x, float* dw_db, in
 int ss_avgpool_bwd(int dtype, const void* g, int64_t ldg, void* dx, int64_t ldx, int B, int H, int W, int C, int win, hipStream_t stream);
 int ss_act_bwd(int dtype, const void* dy, const void* y, void* dx, int64_t n, int act, hipStream_t stream);
 int ss_mul(int dtype, const void* a, const void* b, void* out, int64_t n, hipStream_t stream);
+/* InjectionDotSum backward in one pass over the fine map (modules/topformer.py:640-673; out = local * up(gact) + up(gemb)):
+ * dlocal = g * up(gact), dgact = up^T(g * local), dgemb = up^T(g), up = the bilinear resize of ss_bilinear_fwd by an even integer factor.
+ * g, local, dlocal dense [B*hl*wl][C]; gact / dgact / dgemb [B*hg*wg][C] with row pitches.  ss_inject_bwd_ok says whether the geometry is
+ * taken (else: ss_bilinear_fwd + ss_mul + ss_bilinear_bwd).  workspace >= B (hg+1) (wg+1) 8 C floats. */
+int ss_inject_bwd_ok(int hl, int wl, int hg, int wg, int C);
+int ss_inject_bwd(int dtype, const void* g, const void* local, const void* gact, int64_t lda, void* dlocal, void* dgact, int64_t ldda,
+                  void* dgemb, int64_t ldde, int B, int hl, int wl, int hg, int wg, int C, float* workspace, int64_t ws_bytes,
+                  hipStream_t stream);
 /* RefinerHead in train mode (modules/heads.py:22-39, :173-269).
  * ss_simam_bwd: gradient of ss_simam_apply w.r.t. x (through the mean and the variance as well) and w.r.t. the learnable k
  *   (dk, one float, += when accumulate_dk); moments as ss_image_moments(x); sums: [images][2][C] fp32 scratch;

@@ -13,6 +13,7 @@
 // reductions in fixed order (no floating-point atomics).
 #include "common.h"
 #include "colreduce.h"
+#include "bilinear.h"
 
 namespace {
 
@@ -351,6 +352,115 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
 
 inline int64_t tt_bpi(int64_t rows, int C) { int64_t b = cdiv(rows * (C / 8), 256 * 4); return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
 
+
+// ------------------------------------------------------------------ InjectionDotSum backward in one pass (modules/topformer.py:640-673)
+// out = local * up(gact) + up(gemb)  =>  dlocal = g * up(gact),  dgact = up^T(g * local),  dgemb = up^T(g),  up = bilinear resize by an
+// even integer factor r.  The transposed resize is a weighted sum over 2r x 2r output pixels per coarse pixel; done as a gather per
+// coarse pixel (ss_bilinear_bwd) every g element is fetched four times, twice over (two maps) and the product g * local makes a round
+// trip through memory.  Here the fine map is cut into cells of r x r pixels shifted by r/2 (cell (jb, kb): rows [r jb - r/2, r jb + r/2)):
+// all pixels of a cell share their four coarse taps (rows jb-1 / jb, columns kb-1 / kb, clamped), so a workgroup reads its cell of g and
+// local ONCE, writes dlocal, and leaves eight partial sums per channel -- (g, g * local) x four taps; a second small kernel gives each
+// coarse pixel the four cells around it, in a fixed order.  Weights come from lin_tap, the taps ss_bilinear_fwd uses.
+template <typename T>
+__global__ __launch_bounds__(256) void inject_bwd_kernel(const T* __restrict__ g, const T* __restrict__ local, const T* __restrict__ gact, int64_t lda,
+                                                         T* __restrict__ dlocal, float* __restrict__ partial, int hl, int wl, int hg, int wg, int C, int r,
+                                                         int nl) {
+    __shared__ float red[256 * 8];
+    const int cell = blockIdx.x, kb = cell % (wg + 1), jb = (cell / (wg + 1)) % (hg + 1), b = cell / ((wg + 1) * (hg + 1));
+    const int chunks = C / 8, tid = threadIdx.x, ch = tid % chunks, pl = tid / chunks;
+    const bool active = pl < nl;
+    const int oy0 = max(0, r * jb - r / 2), oy1 = min(hl, r * jb + r / 2), ox0 = max(0, r * kb - r / 2), ox1 = min(wl, r * kb + r / 2);
+    const int rlo = max(jb - 1, 0), rhi = min(jb, hg - 1), clo = max(kb - 1, 0), chi = min(kb, wg - 1);
+    const float sh = (float)hg / hl, sw = (float)wg / wl;
+    float acc[2][4][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[q][s][e] = 0.f;
+    if (active) {
+        const LinTap ty0 = lin_tap(oy0, sh, hg), tx0 = lin_tap(ox0, sw, wg);          // the cell's taps (weights differ per pixel, indices do not)
+        const T* gb = gact + (int64_t)b * hg * wg * lda + ch * 8;
+        const F8 c00 = load8(gb + ((int64_t)ty0.i0 * wg + tx0.i0) * lda), c01 = load8(gb + ((int64_t)ty0.i0 * wg + tx0.i1) * lda);
+        const F8 c10 = load8(gb + ((int64_t)ty0.i1 * wg + tx0.i0) * lda), c11 = load8(gb + ((int64_t)ty0.i1 * wg + tx0.i1) * lda);
+        const int bw = ox1 - ox0, npx = (oy1 - oy0) * bw;
+        for (int p = pl; p < npx; p += nl) {
+            const int oy = oy0 + p / bw, ox = ox0 + p % bw;
+            const LinTap ty = lin_tap(oy, sh, hg), tx = lin_tap(ox, sw, wg);
+            const float wyl = (ty.i0 == rlo ? ty.l0 : 0.f) + (ty.i1 == rlo ? ty.l1 : 0.f);
+            const float wyh = rhi != rlo ? (ty.i0 == rhi ? ty.l0 : 0.f) + (ty.i1 == rhi ? ty.l1 : 0.f) : 0.f;
+            const float wxl = (tx.i0 == clo ? tx.l0 : 0.f) + (tx.i1 == clo ? tx.l1 : 0.f);
+            const float wxh = chi != clo ? (tx.i0 == chi ? tx.l0 : 0.f) + (tx.i1 == chi ? tx.l1 : 0.f) : 0.f;
+            const float w[4] = {wyl * wxl, wyl * wxh, wyh * wxl, wyh * wxh};
+            const int64_t idx = (((int64_t)b * hl + oy) * wl + ox) * C + ch * 8;
+            const F8 gv = load8(g + idx), lv = load8(local + idx);
+            F8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float u = to_f(from_f<T>(bilerp(ty, tx, c00.v[e], c01.v[e], c10.v[e], c11.v[e])));      // the value ss_bilinear_fwd stores
+                o.v[e] = gv.v[e] * u;
+                const float q = gv.v[e] * lv.v[e];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { acc[0][s][e] = fmaf(w[s], gv.v[e], acc[0][s][e]); acc[1][s][e] = fmaf(w[s], q, acc[1][s][e]); }
+            }
+            store8(dlocal + idx, o);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[q][s][e];
+            __syncthreads();
+            if (pl == 0) {
+                float* dst = partial + (((int64_t)cell * 2 + q) * 4 + s) * C + ch * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float sum = 0.f;
+                    for (int j = 0; j < nl; ++j) sum += red[(j * chunks + ch) * 8 + e];
+                    dst[e] = sum;
+                }
+            }
+        }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void inject_bwd_final_kernel(const float* __restrict__ partial, T* __restrict__ dgact, int64_t lda, T* __restrict__ dgemb,
+                                                               int64_t lde, int B, int hg, int wg, int C) {
+    const int chunks = C / 8;
+    const int64_t items = (int64_t)B * hg * wg * chunks;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(it % chunks);
+        int64_t p = it / chunks;
+        const int ix = (int)(p % wg); p /= wg;
+        const int iy = (int)(p % hg);
+        const int b = (int)(p / hg);
+        F8 s0 = zero8(), s1 = zero8();
+        for (int jb = iy; jb <= iy + 1; ++jb) {
+            const int rlo = max(jb - 1, 0), rhi = min(jb, hg - 1);
+            for (int vs = 0; vs < 2; ++vs) {
+                if (vs == 0 ? rlo != iy : (rhi != iy || rhi == rlo)) continue;
+                for (int kb = ix; kb <= ix + 1; ++kb) {
+                    const int clo = max(kb - 1, 0), chi = min(kb, wg - 1);
+                    for (int hs = 0; hs < 2; ++hs) {
+                        if (hs == 0 ? clo != ix : (chi != ix || chi == clo)) continue;
+                        const int64_t cell = ((int64_t)b * (hg + 1) + jb) * (wg + 1) + kb;
+                        const F8 a = load8(partial + ((cell * 2 + 0) * 4 + vs * 2 + hs) * C + ch * 8);
+                        const F8 q = load8(partial + ((cell * 2 + 1) * 4 + vs * 2 + hs) * C + ch * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { s0.v[e] += a.v[e]; s1.v[e] += q.v[e]; }
+                    }
+                }
+            }
+        }
+        const int64_t row = ((int64_t)b * hg + iy) * wg + ix;
+        store8(dgemb + row * lde + ch * 8, s0);
+        store8(dgact + row * lda + ch * 8, s1);
+    }
+}
+
 }  // namespace
 
 // g [B*Ho*Wo, C] -> dx [B*H*W, C]; wkkc: tap-major [k*k, C] fp32 (NOT flipped: the kernel walks the taps of the forward)
@@ -484,6 +594,36 @@ extern "C" int ss_groupnorm_bwd(const float* dy, int64_t ldd, const float* x, in
                            rows_per_image, ncol, (int)bpi); } while (0)
     if (pre_act == 5) SS_GNB(true); else SS_GNB(false);
 #undef SS_GNB
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- InjectionDotSum backward (see inject_bwd_kernel).  g, local, dlocal: dense [B*hl*wl][C]; gact, dgact, dgemb: [B*hg*wg][C] with row
+// pitches lda / ldda / ldde.  hl = r hg, wl = r wg with r even; C % 8 == 0, C <= 2048.  workspace >= B (hg+1) (wg+1) 8 C floats.
+extern "C" int ss_inject_bwd_ok(int hl, int wl, int hg, int wg, int C) {
+    if (hg <= 0 || wg <= 0 || hl % hg || wl % wg || hl / hg != wl / wg) return 0;
+    const int r = hl / hg;
+    return r >= 2 && r % 2 == 0 && C % 8 == 0 && C >= 8 && C <= 2048;
+}
+extern "C" int ss_inject_bwd(int dtype, const void* g, const void* local, const void* gact, int64_t lda, void* dlocal, void* dgact, int64_t ldda,
+                             void* dgemb, int64_t ldde, int B, int hl, int wl, int hg, int wg, int C, float* workspace, int64_t ws_bytes,
+                             hipStream_t stream) {
+    SS_CHECK(g && local && gact && dlocal && dgact && dgemb && workspace && B > 0 && ss_inject_bwd_ok(hl, wl, hg, wg, C),
+             "ss_inject_bwd: need hl = r hg, wl = r wg with an even r >= 2 and C %% 8 == 0 (hl=%d wl=%d hg=%d wg=%d C=%d)", hl, wl, hg, wg, C);
+    SS_CHECK(lda >= C && ldda >= C && ldde >= C && lda % 8 == 0 && ldda % 8 == 0 && ldde % 8 == 0 && aligned16(g) && aligned16(local) && aligned16(gact) &&
+             aligned16(dlocal) && aligned16(dgact) && aligned16(dgemb), "ss_inject_bwd: rows must be 16-byte aligned");
+    const int64_t cells = (int64_t)B * (hg + 1) * (wg + 1);
+    SS_CHECK(cells < (1ll << 31) && ws_bytes >= cells * 8 * C * 4, "ss_inject_bwd: workspace too small");
+    const int r = hl / hg, chunks = C / 8;
+    int nl = 256 / chunks; if (nl < 1) nl = 1; if (nl > r * r) nl = r * r;
+    SS_CHECK(chunks <= 256, "ss_inject_bwd: C too large");
+    const int64_t items = (int64_t)B * hg * wg * chunks;
+    SS_DISPATCH(dtype, {
+        hipLaunchKernelGGL((inject_bwd_kernel<T>), dim3((unsigned)cells), dim3(256), 0, stream, (const T*)g, (const T*)local, (const T*)gact, lda, (T*)dlocal,
+                           workspace, hl, wl, hg, wg, C, r, nl);
+        hipLaunchKernelGGL((inject_bwd_final_kernel<T>), dim3(tt_blocks(items, 4096)), dim3(256), 0, stream, (const float*)workspace, (T*)dgact, ldda, (T*)dgemb,
+                           ldde, B, hg, wg, C);
+    });
     SS_LAUNCH_CHECK();
     return 0;
 }

@@ -1593,6 +1593,26 @@ def mul(a, b):
     return out
 
 
+def inject_bwd(g, local, gact, B, hl, wl, hg, wg):
+    """InjectionDotSum backward -> (dlocal, dgact, dgemb); one pass over the fine map where ss_inject_bwd takes the geometry, else the resize,
+    two products and two transposed resizes."""
+    dev = _dev(g)
+    rows, C, ldg = _mat(g, 'g')
+    ra, Ca, lda = _mat(gact, 'gact')
+    if rows != B * hl * wl or ra != B * hg * wg or Ca != C or local.shape != g.shape or local.dtype != g.dtype or gact.dtype != g.dtype:
+        raise ValueError('inject_bwd: bad shapes')
+    if not (lib().ss_inject_bwd_ok(hl, wl, hg, wg, C) and g.is_contiguous() and local.is_contiguous()):
+        dlocal = mul(g, bilinear_fwd(gact, B, hg, wg, hl, wl))
+        return dlocal, bilinear_bwd(mul(g, local), B, hg, wg, hl, wl), bilinear_bwd(g, B, hg, wg, hl, wl)
+    dlocal = torch.empty_like(g)
+    dgact = torch.empty((ra, C), dtype=g.dtype, device=dev)
+    dgemb = torch.empty((ra, C), dtype=g.dtype, device=dev)
+    ws = workspace(dev, B * (hg + 1) * (wg + 1) * 8 * C * 4)
+    check(lib().ss_inject_bwd(dt(g), _p(g), _p(local), _p(gact), lda, _p(dlocal), _p(dgact), C, _p(dgemb), C, B, hl, wl, hg, wg, C, _p(ws), ws.numel(),
+                              _stream()))
+    return dlocal, dgact, dgemb
+
+
 def simam_bwd(dy, x, moments, k, images, dk, accumulate_dk=True):
     """-> dx (like x); dk (one fp32) is written or accumulated in place."""
     dev = _dev(x)

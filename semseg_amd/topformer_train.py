@@ -18,7 +18,8 @@ Layer by layer (reference file:line):
   with q / k zero-padded to the value head width (padding channels: zero weight rows and gamma = beta = 0, so they stay exactly zero
   through BatchNorm and receive exactly zero gradient).
 * FFN (:236-327): conv-BN -> depthwise 3x3 (bias) -BN-ReLU6 -> conv-BN, residual in the last BatchNorm's apply pass.
-* InjectionDotSum (:640-673): ss_inject_fuse forward; backward ss_bilinear_fwd (recomputed up-sampled gate) + ss_mul + ss_bilinear_bwd.
+* InjectionDotSum (:640-673): ss_inject_fuse forward; backward ss_inject_bwd (one pass over the fine map: the three gradients from one read
+  of g and local; other geometries: ss_bilinear_fwd + ss_mul + ss_bilinear_bwd).
 * SimpleHead (modules/heads.py:120-170) and the classifier (core/models.py:103-115): UniRes + Sum / Concat, conv-BN-ReLU6, then the 1x1
   classifier BEFORE the final bilinear resize (both linear; exact in real arithmetic).
 * RefinerHead (modules/heads.py:173-269): SimAM (ss_image_moments + ss_simam_apply / ss_simam_bwd), the grouped 1x1 conv per stage
@@ -26,6 +27,8 @@ Layer by layer (reference file:line):
   fixed-pattern matrix, GroupNorm(num_classes groups), classifier; fp32 from the group conv on.
 DropPath rate is 0 in every reference config (modules/topformer.py:1121-1378) and there is no Dropout on this path.
 """
+import os
+
 import torch
 
 from . import ops
@@ -88,6 +91,13 @@ def _bn_args(bn):
     return bn.weight.detach(), bn.bias.detach(), float(bn.eps), float(bn.momentum)
 
 
+def _conv_bn_fwd(x, w, bn, res=None, act=0):
+    """1x1 conv and the batch statistics of its output from one pass (the GEMM's copy-out, where the tile kernels take the shape)"""
+    gamma, beta, eps, mom = _bn_args(bn)
+    z, stats = ops.gemm_nt_bn_stats(x, w, eps=eps, momentum=mom, running_mean=bn.running_mean, running_var=bn.running_var, nbt=bn.num_batches_tracked)
+    return z, ops.bn_apply(z, stats, gamma, beta, act=act, res=res), stats
+
+
 def _bn_fwd(z, bn, res=None, out=None, act=0):
     gamma, beta, eps, mom = _bn_args(bn)
     stats = ops.bn_stats(z, eps, mom, bn.running_mean, bn.running_var, bn.num_batches_tracked)
@@ -102,8 +112,7 @@ def conv_bn(tape, x, unit, res=None, need_dx=True, defer_dx=False):
         raise NotImplementedError('conv_bn: 1x1 bias-free conv-norm-act units only')
     O = conv.weight.shape[0]
     w2 = conv.weight.detach().reshape(O, -1)
-    z = ops.gemm_nt(x.t, tape.wmat(w2))
-    y, stats = _bn_fwd(z, bn, res=res.t if res is not None else None, act=unit.act)      # ReLU / ReLU6 inside the normalisation pass
+    z, y, stats = _conv_bn_fwd(x.t, tape.wmat(w2), bn, res=res.t if res is not None else None, act=unit.act)      # ReLU / ReLU6 inside the normalisation pass
     out = _V(y)
 
     def bwd():
@@ -136,7 +145,10 @@ def dw_bn(tape, x, unit, B, H, W):
     def bwd():
         dz, dgb = ops.bn_bwd(out.g, z, stats, bn.weight.detach(), bn.bias.detach(), act=unit.act)
         tape.pg(bn.weight, dgb[0]), tape.pg(bn.bias, dgb[1])
-        dwdb = ops.dwconvk_wgrad_s(dz, x.t, B, H, W, k, s, p0, p0, Ho, Wo)
+        if s == 1 and p0 == k // 2 and os.environ.get('SS_TOP_WGRAD', 'tile') == 'tile':   # stride 1, symmetric padding: the LDS-tiled kernel of the ConvNeXt path
+            dwdb = ops.dwconvk_wgrad(dz, x.t, B, H, W, k)
+        else:
+            dwdb = ops.dwconvk_wgrad_s(dz, x.t, B, H, W, k, s, p0, p0, Ho, Wo)
         tape.pg(conv.weight, ops.transpose_cast(dwdb[:k * k], F32))
         if conv.bias is not None:
             tape.pg(conv.bias, dwdb[k * k])
@@ -154,8 +166,7 @@ def stem(tape, x, unit):
     t = ops.nchw_to_nhwc(x.contiguous().float(), tape.T)
     col = ops.im2col_ex(t, B, H, W, cin, 3, 2, pt, pt, h, w)
     wp, _ = ops.pack_conv_weight(conv.weight.detach().float().contiguous(), tape.T, transposed=False)
-    z = ops.gemm_nt(col, wp)
-    y, stats = _bn_fwd(z, bn, act=unit.act)
+    z, y, stats = _conv_bn_fwd(col, wp, bn, act=unit.act)
     out = _V(y)
 
     def bwd():
@@ -219,9 +230,8 @@ def attention(tape, tok, attn, B, n, nh, kd, d):
     ao, lse = ops.mit_attn_fwd(q, kv, B, n, n, nh, scale=1.0)
     a = ops.act(ao, pj.act)
     wp = cw(pj)
-    zp = ops.gemm_nt(a, tape.wmat(wp))
     bnp = pj.net.norm
-    y, stats_p = _bn_fwd(zp, bnp, res=x)
+    zp, y, stats_p = _conv_bn_fwd(a, tape.wmat(wp), bnp, res=x)
     out = _V(y)
 
     def bwd():
@@ -297,10 +307,8 @@ def backbone(tape, net, x):
         out = _V(ops.inject_fuse(local.t, ga.t, ge.t, B, ph, pw, hg, wg))
 
         def inj_bwd(out=out, local=local, ga=ga, ge=ge, ph=ph, pw=pw):
-            g = out.g
-            tape.acc(local, ops.mul(g, ops.bilinear_fwd(ga.t, B, hg, wg, ph, pw)))
-            tape.acc(ga, ops.bilinear_bwd(ops.mul(g, local.t), B, hg, wg, ph, pw))
-            tape.acc(ge, ops.bilinear_bwd(g, B, hg, wg, ph, pw))
+            dlocal, dga, dge = ops.inject_bwd(out.g, local.t, ga.t, B, ph, pw, hg, wg)
+            tape.acc(local, dlocal), tape.acc(ga, dga), tape.acc(ge, dge)
         tape.push(inj_bwd)
         outs.append((out, ph, pw))
     return outs

@@ -326,3 +326,28 @@ def test_groupnorm_fwd_bwd_vs_torch(groups, cg, pitch, pre):
     assert rel(dgb[0], gn.weight.grad) < 2e-5 and rel(dgb[1], gn.bias.grad) < 2e-5
     if bool(pad.any()):
         assert float(dx[:, pad].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C,r,hg,wg', [(256, 16, 2, 3), (128, 8, 4, 6), (192, 4, 3, 5), (64, 2, 8, 4), (8, 2, 1, 1), (256, 6, 2, 2)])
+def test_injection_backward_in_one_pass(dtype, C, r, hg, wg):
+    """ss_inject_bwd (dlocal, dgact, dgemb from one read of g and local) against autograd of local * up(gact) + up(gemb) in torch fp32
+    (F.interpolate bilinear, align_corners=False) and against the five launches it replaces; dlocal is bit-identical to those."""
+    from semseg_amd import ops
+    B, hl, wl = 2, r * hg, r * wg
+    gen = torch.Generator().manual_seed(C + r)
+    mk = lambda n: torch.randn(n, C, generator=gen).cuda().to(dtype)
+    g, local, gact = mk(B * hl * wl), mk(B * hl * wl), mk(B * hg * wg)
+    dlocal, dgact, dgemb = ops.inject_bwd(g, local, gact, B, hl, wl, hg, wg)
+    nchw = lambda t, h, w: t.float().view(B, h, w, C).permute(0, 3, 1, 2)
+    lo, ga, ge = nchw(local, hl, wl).requires_grad_(True), nchw(gact, hg, wg).requires_grad_(True), torch.zeros(B, C, hg, wg, device='cuda', requires_grad=True)
+    up = lambda t: F.interpolate(t, size=(hl, wl), mode='bilinear', align_corners=False)
+    (lo * up(ga) + up(ge)).backward(nchw(g, hl, wl))
+    tol = 2e-5 if dtype == torch.float32 else 8e-3
+    assert rel(nchw(dlocal, hl, wl), lo.grad) < tol
+    assert rel(nchw(dgact, hg, wg), ga.grad) < tol
+    assert rel(nchw(dgemb, hg, wg), ge.grad) < tol
+    old = ops.mul(g, ops.bilinear_fwd(gact, B, hg, wg, hl, wl))
+    assert torch.equal(dlocal, old)
+    assert rel(dgemb, ops.bilinear_bwd(g, B, hg, wg, hl, wl)) < tol

@@ -2,7 +2,7 @@
 2: no operand fills after the first, 4: no MFMA)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ['SS_GEMM_BIG'] = '1'
+os.environ['SS_GEMM_BIG'] = '1'           # the two-stage form carries the switches
 import torch
 from semseg_amd import ops
 
