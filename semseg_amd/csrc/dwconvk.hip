@@ -7,6 +7,7 @@
 //   wgrad    : dW[ky][kx][c] = sum_p g[p][c] x[p + (ky, kx) - pad][c], db = sum_p g; one launch row per ky so a thread keeps
 //              k x 8 accumulators; per-workgroup partials, fixed-order final reduce (deterministic).
 #include "common.h"
+#include <stdlib.h>
 #include "colreduce.h"
 
 template <typename T>
@@ -297,6 +298,148 @@ __global__ __launch_bounds__(256) void dwconvk_wgrad_tile_kernel(const T* __rest
     if (lane == 0) { dst[K * K * C] = b0; dst[K * K * C + 1] = b1; }
 }
 
+// ---- stride-1 weight gradient on the matrix cores (bf16; k = 3, 5, 7; C % 32 == 0).
+// Per channel, dW[ky][kx] = sum_{r, x} X[r][x - pad + kx] * g[r + pad - ky][x] is, for one input row r and four consecutive columns,
+// a (kx x 4) . (4 x ky) product: v_mfma_f32_4x4x4_16B_bf16 does SIXTEEN such 4 x 4 x 4 products per wave instruction, one per channel
+// (block b = lanes 4b .. 4b+3): lane 4b + i holds A[i][0..3] = X[r][x0 - pad + i + 0..3] (row kx = i of a Toeplitz matrix), lane 4b + j
+// holds B[0..3][j] = g[r + pad - j][x0 + 0..3], and register i of lane 4b + j receives dW[ky = j][kx = i].  Taps are padded to 4 x 4
+// (k = 3) or 8 x 8 (k = 5, 7: A and B each in two halves, four instructions): 49 useful of 64 products at k = 7, at 11 clocks per
+// instruction -- the vector ALUs need 784 fmas per thread for what is here 4 x 8 instructions per wave.
+// Channels-last memory has a channel's neighbouring pixels C elements apart, so a workgroup (32 channels x 64 columns, walking down a
+// strip of rows) transposes through LDS: per input row, threads load 16-byte channel chunks of two or three neighbouring pixels and store
+// (pixel, pixel + 1) PAIRS as dwords into per-channel planes -- X twice, once shifted by one element, so that the window of lane i
+// (starting at element x0 + i) is two ALIGNED dwords of copy i & 1.  g rows live in a ring of eight (the window of k rows above the
+// current input row); one barrier per row, the next row's global loads are in flight during the products.
+typedef __attribute__((ext_vector_type(4))) short short4v;
+
+template <int K>
+__global__ __launch_bounds__(256) void dwk_wgrad_mfma_kernel(const bf16* __restrict__ g, const bf16* __restrict__ x, float* __restrict__ partial, int H, int W,
+                                                            int C, int tiles_x, int nsy, int SR) {
+    constexpr int PAD = K / 2, TC = 64, NH = (K + 3) / 4;
+    constexpr int XW = 76, XPS = 2 * XW;              // X plane [buf][XW] per (copy, channel): 304 bytes apart (48 mod 256: 16 planes, 16 distinct 16-byte bank slots)
+    constexpr int GPS = 8 * TC + 8;                   // g plane [8 ring rows][64] per channel, 1040 bytes apart
+    __shared__ __attribute__((aligned(16))) bf16 Xp[2 * 32 * XPS];
+    __shared__ __attribute__((aligned(16))) bf16 Gp[32 * GPS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = blockIdx.x % tiles_x, sy = (blockIdx.x / tiles_x) % nsy, b = blockIdx.x / (tiles_x * nsy);
+    const int cbase = blockIdx.y * 32, x_t0 = tx * TC, y0 = sy * SR, y1 = min(H, y0 + SR);
+    const bf16* ximg = x + (int64_t)b * H * W * C + cbase;
+    const bf16* gimg = g + (int64_t)b * H * W * C + cbase;
+
+    // loader roles: threads 0 .. 151 pixel pairs of the X row (38 pairs x 4 chunks), threads 128 .. 255 pixel pairs of the g row (32 x 4)
+    const bool xrole = tid < 152, grole = tid >= 128;
+    const int xpu = tid >> 2, xcq = tid & 3, gpg = (tid - 128) >> 2, gcq = tid & 3;
+    bf16x8 xv[3], gv[2];
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto fetch = [&](int r) {                          // input row r and the g row r + PAD that enters the window with it
+        if (xrole) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int gx = x_t0 - PAD + 2 * xpu + u;
+                xv[u] = (r >= 0 && r < H && gx >= 0 && gx < W) ? *(const bf16x8*)(ximg + ((int64_t)r * W + gx) * C + xcq * 8) : z8;
+            }
+        }
+        if (grole) {
+            const int oy = r + PAD;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int gx = x_t0 + 2 * gpg + u;
+                gv[u] = (oy >= y0 && oy < y1 && gx < W) ? *(const bf16x8*)(gimg + ((int64_t)oy * W + gx) * C + gcq * 8) : z8;
+            }
+        }
+    };
+    float bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+    auto stash = [&](int r) {
+        const int buf = r & 1;
+        if (xrole) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bf16x2 p0, p1; p0[0] = xv[0][e]; p0[1] = xv[1][e]; p1[0] = xv[1][e]; p1[1] = xv[2][e];
+                const int ch = xcq * 8 + e;
+                *(bf16x2*)(Xp + (0 * 32 + ch) * XPS + buf * XW + 2 * xpu) = p0;
+                *(bf16x2*)(Xp + (1 * 32 + ch) * XPS + buf * XW + 2 * xpu) = p1;
+            }
+        }
+        if (grole) {
+            const int slot = (r + PAD) & 7;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bf16x2 p; p[0] = gv[0][e]; p[1] = gv[1][e];
+                *(bf16x2*)(Gp + (gcq * 8 + e) * GPS + slot * TC + 2 * gpg) = p;
+                bs[e] += (float)gv[0][e] + (float)gv[1][e];
+            }
+        }
+    };
+    for (int i = tid; i < 32 * GPS / 2; i += 256) ((unsigned*)Gp)[i] = 0u;      // rows above the strip are zero
+    __syncthreads();
+
+    // product roles: wave = (column half q, channel half h); lane = (channel blk, tap index i)
+    const int h = wave & 1, q = wave >> 1, blk = lane >> 2, i = lane & 3, ch = h * 16 + blk;
+    const bf16* xa = Xp + ((i & 1) * 32 + ch) * XPS + (i & ~1) + q * 32;
+    const bf16* gb = Gp + ch * GPS + q * 32;
+    floatx4 D[NH][NH];
+#pragma unroll
+    for (int a = 0; a < NH; ++a)
+#pragma unroll
+        for (int c = 0; c < NH; ++c) D[a][c] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int r0 = y0 - PAD, r1 = y1 - 1 + PAD;
+    fetch(r0);
+    for (int r = r0; r <= r1; ++r) {
+        stash(r);
+        __syncthreads();                               // row r is in LDS; everyone has finished row r - 1 (whose X buffer the next stash reuses)
+        if (r < r1) fetch(r + 1);
+        const bf16* xr = xa + (r & 1) * XW;
+        int slot[NH];
+#pragma unroll
+        for (int hb = 0; hb < NH; ++hb) slot[hb] = ((r + PAD - (i + 4 * hb)) & 7) * TC;
+#pragma unroll
+        for (int xg = 0; xg < 8; ++xg) {
+            short4v A[NH], Bm[NH];
+#pragma unroll
+            for (int ha = 0; ha < NH; ++ha) {
+                const unsigned* p = (const unsigned*)(xr + xg * 4 + 4 * ha);
+                union { unsigned u[2]; short4v v; } t; t.u[0] = p[0]; t.u[1] = p[1]; A[ha] = t.v;
+            }
+#pragma unroll
+            for (int hb = 0; hb < NH; ++hb) Bm[hb] = *(const short4v*)(gb + slot[hb] + xg * 4);
+#pragma unroll
+            for (int hb = 0; hb < NH; ++hb)
+#pragma unroll
+                for (int ha = 0; ha < NH; ++ha) D[hb][ha] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(A[ha], Bm[hb], D[hb][ha], 0, 0, 0);
+        }
+    }
+    // register kx' of lane (channel, ky') of D[hb][ha] is dW[ky = ky' + 4 hb][kx = kx' + 4 ha]
+    float* dst = partial + (int64_t)(blockIdx.x * 2 + q) * (K * K + 1) * C + cbase + ch;
+#pragma unroll
+    for (int hb = 0; hb < NH; ++hb)
+#pragma unroll
+        for (int ha = 0; ha < NH; ++ha)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const int ky = i + 4 * hb, kxx = kx + 4 * ha;
+                if (ky < K && kxx < K) dst[(int64_t)(ky * K + kxx) * C] = D[hb][ha][kx];
+            }
+    // bias gradient: the g loaders' column sums, combined per channel chunk in a fixed order (the g ring is dead by now)
+    __syncthreads();
+    float* red = (float*)Gp;
+    if (grole) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid - 128) * 8 + e] = bs[e];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int cq = tid >> 3, e = tid & 7;
+        float s2 = 0.f;
+        for (int pg = 0; pg < 32; ++pg) s2 += red[(pg * 4 + cq) * 8 + e];
+        float* db = partial + (int64_t)(blockIdx.x * 2) * (K * K + 1) * C + (int64_t)K * K * C + cbase + tid;
+        db[0] = s2;
+        db[(int64_t)(K * K + 1) * C] = 0.f;
+    }
+}
+
 static int dwconvk_fwd_impl(int dtype, const void* x, const float* wkkc, const float* bias, void* y, int B, int H, int W, int C, int k,
                            int stride, int pad_top, int pad_left, int Ho, int Wo, int act, const void* res, hipStream_t stream) {
     SS_CHECK(!res || aligned16(res), "ss_dwconvk_fwd_res: res must be 16-byte aligned");
@@ -341,6 +484,25 @@ extern "C" int ss_dwconvk_wgrad(int dtype, const void* g, const void* x, float* 
     ColGeom geo = col_geom((int64_t)B * H * W, C);
     const int rows = k * k + 1;
     SS_CHECK(ws_bytes >= (int64_t)SS_COLRED_MAX_BLOCKS * rows * C * 4, "ss_dwconvk_wgrad: workspace too small (need 1024 * (k*k + 1) * C floats)");
+    static int mfma_mode = -1;                            // SS_DWK_WGRAD=tile: keep the vector-ALU kernel (A/B runs)
+    if (mfma_mode < 0) { const char* e = getenv("SS_DWK_WGRAD"); mfma_mode = e && e[0] == 't' ? 0 : 1; }
+    if (pad == k / 2 && dtype == SS_BF16 && C % 32 == 0 && mfma_mode) {
+        const int tiles_x = (int)cdiv(W, 64);
+        int SR = 32;
+        while ((int64_t)B * tiles_x * cdiv(H, SR) * 2 > SS_COLRED_MAX_BLOCKS) SR *= 2;
+        const int nsy = (int)cdiv(H, SR);
+        const int64_t strips = (int64_t)B * tiles_x * nsy;
+        if (strips * 2 <= SS_COLRED_MAX_BLOCKS && SR < (1 << 20)) {
+            dim3 grid((unsigned)strips, (unsigned)(C / 32));
+            if (k == 3) hipLaunchKernelGGL((dwk_wgrad_mfma_kernel<3>), grid, dim3(256), 0, stream, (const bf16*)g, (const bf16*)x, workspace, H, W, C, tiles_x, nsy, SR);
+            else if (k == 5) hipLaunchKernelGGL((dwk_wgrad_mfma_kernel<5>), grid, dim3(256), 0, stream, (const bf16*)g, (const bf16*)x, workspace, H, W, C, tiles_x, nsy, SR);
+            else hipLaunchKernelGGL((dwk_wgrad_mfma_kernel<7>), grid, dim3(256), 0, stream, (const bf16*)g, (const bf16*)x, workspace, H, W, C, tiles_x, nsy, SR);
+            SS_LAUNCH_CHECK();
+            hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(rows * C, 8), 1), dim3(256), 0, stream, workspace, (int)(strips * 2), rows * C, 1.f, dw_db, 0);
+            SS_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (pad == k / 2) {                                   // tiled kernel: strips of 64 x 8 tiles, 8 channels per workgroup
         const int tiles_x = (int)cdiv(W, 64), tiles_y = (int)cdiv(H, 8);
         const int64_t ntiles = (int64_t)B * tiles_x * tiles_y;

@@ -735,10 +735,12 @@ def test_dwconvk_stride2_tiled_and_fallback(ops, dtype, k, C, H, W, act):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('k,C,H,W', [(7, 96, 19, 70), (5, 32, 9, 130), (3, 64, 8, 64), (7, 8, 5, 3), (7, 40, 33, 20)])
+@pytest.mark.parametrize('k,C,H,W', [(7, 96, 19, 70), (5, 32, 9, 130), (3, 64, 8, 64), (7, 8, 5, 3), (7, 40, 33, 20), (7, 192, 70, 33), (5, 96, 40, 64),
+                                     (3, 32, 3, 5), (7, 64, 1, 1), (3, 160, 33, 129)])
 def test_dwconvk_weight_gradient(ops, dtype, k, C, H, W):
     """dW, db of a depthwise k x k (stride 1, padding k//2) against torch autograd; strips of several tiles, ragged edges; bitwise
-    reproducible."""
+    reproducible.  bf16 with C % 32 == 0 runs on the matrix cores (dwk_wgrad_mfma_kernel: 16 channels per 4x4x4 MFMA), the rest on the
+    vector-ALU tile kernel."""
     B = 3
     x, g = rnd(B, C, H, W), rnd(B, C, H, W, seed=1)
     w = torch.zeros(C, 1, k, k, requires_grad=True)
