@@ -297,12 +297,12 @@ def roofline_from_table(tab, traffic_ok=False):
         out['algorithmic_bytes_per_launch'] = f['bytes'] / f['calls']
         out['frac_of_per_shape_roofline'] = f['ideal_ms'] / f['ms']
     if name == 'gemm':
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_hbm_traffic.json')
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_pmc_hbm_traffic.json')
         if traffic_ok and os.path.exists(pmc):
             with open(pmc) as fh:
                 g = json.load(fh)['gemm_family']
             out['traffic'] = g['hbm_bytes_per_launch']
-            out['traffic_source'] = 'profiles/r02_pmc_hbm_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this command, tools/profile_pmc.sh)'
+            out['traffic_source'] = 'profiles/r03_pmc_hbm_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this command, tools/profile_pmc.sh)'
     # the five families with the largest share, each against its own bound: `frac` = achieved / peak of the bound it is priced on,
     # `frac_of_per_launch_roofline` = sum of the launches' max(flops / MFMA peak, bytes / HBM peak) over the measured time
     top = []

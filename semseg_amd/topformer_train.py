@@ -152,7 +152,11 @@ def dw_bn(tape, x, unit, B, H, W):
         tape.pg(conv.weight, ops.transpose_cast(dwdb[:k * k], F32))
         if conv.bias is not None:
             tape.pg(conv.bias, dwdb[k * k])
-        tape.acc(x, ops.dwconvk_dgrad(dz, wkkc, B, H, W, k, s, p0, p0, Ho, Wo))
+        if s == 1 and p0 == k // 2:                     # stride 1: the data gradient is the forward kernel (LDS-tiled) with the taps reversed
+            wflip = ops.transpose_cast(conv.weight.detach().reshape(C, k * k).contiguous(), F32, reverse_cols=True)
+            tape.acc(x, ops.dwconvk_fwd(dz, wflip, tape.zeros(C, dz.device), B, H, W, k, 1, k - 1 - p0, k - 1 - p0, H, W, act=0))
+        else:
+            tape.acc(x, ops.dwconvk_dgrad(dz, wkkc, B, H, W, k, s, p0, p0, Ho, Wo))
     tape.push(bwd)
     return out, Ho, Wo
 
