@@ -158,3 +158,45 @@ def test_full_size_mit_b5_2048_ce_dice_step_and_confusion_matrix():
     assert torch.isfinite(both).all()
     assert float((both[0] - one0[0]).abs().max()) <= 2.0 ** -7 * scale
     assert float((both[0] - both[1]).abs().max()) > 1e-3 * scale
+
+
+def test_full_size_topformer_b_refiner_training_step_properties():
+    """The model train.py:45-52 builds (TopFormer-B + RefinerHead) at train.py's tile size, 1024 x 1024, batch 4, bf16: one training step
+    (OHEM-CE) leaves a finite, non-zero gradient in every parameter and advances every BatchNorm's running statistics exactly once; a second
+    step from the same state is bitwise identical (fixed-order reductions everywhere); and in fp32 the gradient is linear in the loss scale
+    (backward(2 L) == 2 backward(L) up to fp32 rounding) -- a property of the whole backward chain that needs no oracle at this size."""
+    from semseg_amd.topformer import TopFormerModel
+    from semseg_amd.loss import OhemCrossEntropyLoss
+    from semseg_amd.runtime import set_compute_dtype
+    from semseg_amd.detinit import det_fill_, det_input, det_labels
+    net = det_fill_(TopFormerModel(6, 'B', head_cfg=frozenset({'alias': 'refiner'}.items()))).cuda().train()
+    x = det_input('full.tx', (4, 3, 1024, 1024), 0, 1).cuda()
+    lab = det_labels('full.tl', (4, 1024, 1024), 6, cell=32).cuda()
+    crit = OhemCrossEntropyLoss(0, 0.7, 0.1)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def step(dtype, scale=1.0):
+        net.load_state_dict(state)
+        net.zero_grad()
+        set_compute_dtype(dtype)
+        try:
+            out = net(x)
+            loss = crit(out, lab) * scale
+            loss.backward()
+        finally:
+            set_compute_dtype(None)
+        return out.detach().float(), float(loss.detach()), {n: p.grad.clone() for n, p in net.named_parameters()}
+
+    out, loss, g1 = step(torch.bfloat16)
+    assert out.shape == (4, 6, 1024, 1024) and bool(torch.isfinite(out).all()) and 1.0 < loss < 3.5
+    assert _dead(net) == []
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            assert int(m.num_batches_tracked) == 1
+    out2, loss2, g2 = step(torch.bfloat16)
+    assert torch.equal(out, out2) and loss == loss2 and all(torch.equal(g1[n], g2[n]) for n in g1)
+    _, la, ga = step(torch.float32)
+    _, lb, gb = step(torch.float32, 2.0)
+    assert abs(lb - 2 * la) < 1e-5 * abs(la)
+    cat = lambda d: torch.cat([d[n].flatten() for n in sorted(d)])
+    assert float((cat(gb) - 2 * cat(ga)).norm() / cat(ga).norm()) < 1e-5
