@@ -31,7 +31,7 @@ import os
 
 import torch
 
-from . import ops
+from . import ops, weightprep
 from .runtime import GradAwareFunction, compute_dtype_for, deliver_grads, expect_grads, recording
 from .topformer import RELU, RELU6, RefinerHead, SimpleHead, auto_pad
 
@@ -76,13 +76,19 @@ class _Tape:
         self.steps = []
 
     # ------------------------------------------------------------------ operand preparation
-    def wmat(self, w2d):
-        """fp32 [O, I] parameter view -> GEMM operand in the compute dtype"""
-        w2d = w2d.contiguous()
-        return w2d if self.T == F32 else ops.cast(w2d, self.T)
+    def wmat(self, w):
+        """conv weight [O, I, 1, 1] (a Parameter: the compute-dtype copy is remembered across steps and refreshed with all others in one
+        launch, weightprep.py) or a derived fp32 [O, I] matrix -> GEMM operand [O, I] in the compute dtype"""
+        if isinstance(w, torch.nn.Parameter):
+            return weightprep.cast(w, self.T)
+        w = w.contiguous()
+        return w if self.T == F32 else ops.cast(w, self.T)
 
-    def wmat_t(self, w2d):
-        return ops.transpose_cast(w2d.contiguous(), self.T)
+    def wmat_t(self, w):
+        """-> [I, O] in the compute dtype (the data-gradient GEMM's operand)"""
+        if isinstance(w, torch.nn.Parameter):
+            return weightprep.transpose(w, w.shape[0], w.numel() // w.shape[0], self.T)
+        return ops.transpose_cast(w.contiguous(), self.T)
 
 
 def _bn_args(bn):
@@ -110,8 +116,7 @@ def conv_bn(tape, x, unit, res=None, need_dx=True, defer_dx=False):
     conv, bn = unit.net.p_conv.conv, unit.net.norm
     if conv.bias is not None or unit.k != 1 or unit.order != 'CNA':
         raise NotImplementedError('conv_bn: 1x1 bias-free conv-norm-act units only')
-    O = conv.weight.shape[0]
-    w2 = conv.weight.detach().reshape(O, -1)
+    w2 = conv.weight
     z, y, stats = _conv_bn_fwd(x.t, tape.wmat(w2), bn, res=res.t if res is not None else None, act=unit.act)      # ReLU / ReLU6 inside the normalisation pass
     out = _V(y)
 
@@ -134,7 +139,7 @@ def dw_bn(tape, x, unit, B, H, W):
     """depthwise k x k (stride 1 / 2, AutoPadding) + BatchNorm + unit.act -> (out, Ho, Wo)"""
     conv, bn = unit.net.p_conv.conv, unit.net.norm
     C, k, s = conv.weight.shape[0], unit.k, unit.stride
-    wkkc = ops.transpose_cast(conv.weight.detach().reshape(C, k * k).contiguous(), F32)
+    wkkc = weightprep.transpose(conv.weight, C, k * k, F32)
     bias = conv.bias.detach() if conv.bias is not None else tape.zeros(C, x.t.device)
     p0, _ = auto_pad(k, s)
     Ho, Wo = H // s, W // s
@@ -153,7 +158,7 @@ def dw_bn(tape, x, unit, B, H, W):
         if conv.bias is not None:
             tape.pg(conv.bias, dwdb[k * k])
         if s == 1 and p0 == k // 2:                     # stride 1: the data gradient is the forward kernel (LDS-tiled) with the taps reversed
-            wflip = ops.transpose_cast(conv.weight.detach().reshape(C, k * k).contiguous(), F32, reverse_cols=True)
+            wflip = weightprep.transpose(conv.weight, C, k * k, F32, reverse_cols=True)
             tape.acc(x, ops.dwconvk_fwd(dz, wflip, tape.zeros(C, dz.device), B, H, W, k, 1, k - 1 - p0, k - 1 - p0, H, W, act=0))
         else:
             tape.acc(x, ops.dwconvk_dgrad(dz, wkkc, B, H, W, k, s, p0, p0, Ho, Wo))
@@ -169,7 +174,7 @@ def stem(tape, x, unit):
     h, w = H // 2, W // 2
     t = ops.nchw_to_nhwc(x.contiguous().float(), tape.T)
     col = ops.im2col_ex(t, B, H, W, cin, 3, 2, pt, pt, h, w)
-    wp, _ = ops.pack_conv_weight(conv.weight.detach().float().contiguous(), tape.T, transposed=False)
+    wp = weightprep.pack(conv.weight, tape.T, transposed=False)
     z, y, stats = _conv_bn_fwd(col, wp, bn, act=unit.act)
     out = _V(y)
 
@@ -233,7 +238,7 @@ def attention(tape, tok, attn, B, n, nh, kd, d):
     _, stats_v = _bn_fwd(zkv[:, Cq:], bnv, out=kv[:, Cq:])
     ao, lse = ops.mit_attn_fwd(q, kv, B, n, n, nh, scale=1.0)
     a = ops.act(ao, pj.act)
-    wp = cw(pj)
+    wp = pj.net.p_conv.conv.weight
     bnp = pj.net.norm
     zp, y, stats_p = _conv_bn_fwd(a, tape.wmat(wp), bnp, res=x)
     out = _V(y)
