@@ -94,6 +94,9 @@ class _Tape:
 def _bn_args(bn):
     if bn.momentum is None or not bn.track_running_stats or not bn.affine:
         raise NotImplementedError('TopFormer training on the MI355X path: BatchNorm must be affine with running statistics and a fixed momentum')
+    if not bn.training:
+        raise NotImplementedError('TopFormer training on the MI355X path: a BatchNorm in eval mode inside a model in train mode (frozen statistics) is not '
+                                  'built; call .train() / .eval() on the whole model')
     return bn.weight.detach(), bn.bias.detach(), float(bn.eps), float(bn.momentum)
 
 
@@ -468,6 +471,8 @@ class _TopFormerTrainFn(GradAwareFunction):
 
 def train_forward(model, x):
     """TopFormerModel.forward in train mode -> logits [B, nc, H, W] (a channels-last view), differentiable w.r.t. every parameter."""
+    if x.requires_grad:
+        raise NotImplementedError('TopFormer training on the MI355X path does not produce a gradient for the input image')
     params = tuple(model.parameters())
     for p in params:
         if p.dtype != F32 or not p.is_contiguous():

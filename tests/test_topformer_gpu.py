@@ -41,8 +41,12 @@ def test_unsupported_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
         TopFormerModel(6, 'B', head_cfg=frozenset({'alias': 'refiner', 'act_cfg': frozenset({'alias': 'relu'}.items())}.items()))
     net = TopFormerModel(6, 'T').train()
-    with pytest.raises((NotImplementedError, RuntimeError)):
+    with pytest.raises(RuntimeError):                # train mode is built (topformer_train.py), but only on a HIP device: no CPU fallback
         net(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(NotImplementedError):         # no gradient for the image
+        net(torch.zeros(1, 3, 64, 64, requires_grad=True))
+    with pytest.raises(NotImplementedError):         # the backbone alone has no training path
+        net.backbone(torch.zeros(1, 3, 64, 64))
 
 
 @pytest.mark.gpu
