@@ -8,6 +8,7 @@
 //              k x 8 accumulators; per-workgroup partials, fixed-order final reduce (deterministic).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "colreduce.h"
 
 template <typename T>
@@ -314,15 +315,19 @@ typedef __attribute__((ext_vector_type(4))) short short4v;
 
 template <int K>
 __global__ __launch_bounds__(256) void dwk_wgrad_mfma_kernel(const bf16* __restrict__ g, const bf16* __restrict__ x, float* __restrict__ partial, int H, int W,
-                                                            int C, int tiles_x, int nsy, int SR) {
+                                                            int C, int tiles_x, int nsy, int SR, int nstrips) {
     constexpr int PAD = K / 2, TC = 64, NH = (K + 3) / 4;
     constexpr int XW = 76, XPS = 2 * XW;              // X plane [buf][XW] per (copy, channel): 304 bytes apart (48 mod 256: 16 planes, 16 distinct 16-byte bank slots)
     constexpr int GPS = 8 * TC + 8;                   // g plane [8 ring rows][64] per channel, 1040 bytes apart
     __shared__ __attribute__((aligned(16))) bf16 Xp[2 * 32 * XPS];
     __shared__ __attribute__((aligned(16))) bf16 Gp[32 * GPS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx = blockIdx.x % tiles_x, sy = (blockIdx.x / tiles_x) % nsy, b = blockIdx.x / (tiles_x * nsy);
-    const int cbase = blockIdx.y * 32, x_t0 = tx * TC, y0 = sy * SR, y1 = min(H, y0 + SR);
+    // (block id = (strip / 8, channel group, strip % 8): the C / 32 workgroups of a strip share an XCD's L2 and run together, see the
+    // forward kernel below)
+    const int groups = C / 32, strip = (blockIdx.x / (8 * groups)) * 8 + (blockIdx.x & 7), cgrp = (blockIdx.x >> 3) % groups;
+    if (strip >= nstrips) return;
+    const int tx = strip % tiles_x, sy = (strip / tiles_x) % nsy, b = strip / (tiles_x * nsy);
+    const int cbase = cgrp * 32, x_t0 = tx * TC, y0 = sy * SR, y1 = min(H, y0 + SR);
     const bf16* ximg = x + (int64_t)b * H * W * C + cbase;
     const bf16* gimg = g + (int64_t)b * H * W * C + cbase;
 
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256) void dwk_wgrad_mfma_kernel(const bf16* __restr
         }
     }
     // register kx' of lane (channel, ky') of D[hb][ha] is dW[ky = ky' + 4 hb][kx = kx' + 4 ha]
-    float* dst = partial + (int64_t)(blockIdx.x * 2 + q) * (K * K + 1) * C + cbase + ch;
+    float* dst = partial + (int64_t)(strip * 2 + q) * (K * K + 1) * C + cbase + ch;
 #pragma unroll
     for (int hb = 0; hb < NH; ++hb)
 #pragma unroll
@@ -434,9 +439,157 @@ __global__ __launch_bounds__(256) void dwk_wgrad_mfma_kernel(const bf16* __restr
         const int cq = tid >> 3, e = tid & 7;
         float s2 = 0.f;
         for (int pg = 0; pg < 32; ++pg) s2 += red[(pg * 4 + cq) * 8 + e];
-        float* db = partial + (int64_t)(blockIdx.x * 2) * (K * K + 1) * C + (int64_t)K * K * C + cbase + tid;
+        float* db = partial + (int64_t)(strip * 2) * (K * K + 1) * C + (int64_t)K * K * C + cbase + tid;
         db[0] = s2;
         db[(int64_t)(K * K + 1) * C] = 0.f;
+    }
+}
+
+// ---- stride-1 forward (and, with reversed taps, data gradient) on the matrix cores (bf16; k = 3, 5, 7; padding k/2; C % 32 == 0).
+// The same 16-channels-per-instruction 4x4x4 MFMA as the weight gradient above, arranged so that NOTHING read from LDS is shifted:
+// for one tap row ky and one ALIGNED group of four input columns u0 + 0..3,
+//   A[i][k] = X[yb + i + ky - pad][u0 + k]          (lane 4b + i: four consecutive inputs of input row yb + i + ky - pad, 8-byte aligned)
+//   B[k][j] = w[ky][kx = u0 + k - (x0 + j) + pad]    (lane 4b + j: the taps that connect those inputs to output column x0 + j; zero outside)
+//   D[i][j] += sum_k A[i][k] B[k][j]                 = y[yb + i][x0 + j], register i of lane 4b + j
+// so the Toeplitz structure sits in the WEIGHT operand, k x 3 constant registers per lane, and a 4 x 4 output block of 16 channels takes
+// 3 k instructions (three aligned groups cover the k + 3 inputs a block of four outputs needs).  A workgroup = 32 channels x 32 columns,
+// walking down its strip four output rows at a time: input rows go global -> registers -> per-channel LDS planes as pixel pairs (a ring
+// of 16 rows), outputs go D -> fp32 LDS planes (bias and activation applied in the register layout, where a lane is a channel) ->
+// channels-last 16-byte stores (+ residual), rounded once.  Weights are rounded to bf16 (what autocast hands the reference's conv2d).
+template <int K>
+__global__ __launch_bounds__(256) void dwk_fwd_mfma_kernel(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const bf16* __restrict__ res, bf16* __restrict__ y, int H, int W, int C, int act, int tiles_x,
+                                                          int nsy, int SR, int ntiles) {
+    // Bank layout of the A reads (lane = channel blk 0..15 x row offset i 0..3, 8 bytes each): rows 88 bytes apart put i = 0, 2 on the first
+    // and i = 1, 3 on the second half of a 16-byte slot, planes 1424 bytes = 9 slots (mod 16) apart put the 16 channels on 16 distinct
+    // slots: every (slot, half) is read by exactly two lanes, the two passes a 512-byte wave read needs anyway.  (With 80-byte rows all
+    // four row offsets of a channel landed on the same half slot: four-way conflicts on the instruction the loop issues most.)
+    constexpr int P = K / 2, TC = 32, OFF = 4, D0 = OFF - P, NG = 3, XW = 44, RING = 16;
+    constexpr int XPS = RING * XW + 8;                // 712 elements
+    constexpr int YPS = 4 * TC + 4;                   // 528 bytes per channel plane: 16 mod 256
+    __shared__ __attribute__((aligned(16))) bf16 Xp[32 * XPS];
+    __shared__ __attribute__((aligned(16))) float Yp[32 * YPS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // A workgroup reads 64 of the C * 2 bytes of each pixel: the C / 32 workgroups of one spatial tile must share an L2 (one XCD, i.e.
+    // block ids congruent mod 8) and run together, or every line is fetched C / 32 times.  id = (tile / 8, channel group, tile % 8).
+    const int groups = C / 32, tile = (blockIdx.x / (8 * groups)) * 8 + (blockIdx.x & 7), cgrp = (blockIdx.x >> 3) % groups;
+    if (tile >= ntiles) return;
+    const int tx = tile % tiles_x, sy = (tile / tiles_x) % nsy, b = tile / (tiles_x * nsy);
+    const int cbase = cgrp * 32, x_t0 = tx * TC, y0 = sy * SR, y1 = min(H, y0 + SR);
+    const bf16* ximg = x + (int64_t)b * H * W * C + cbase;
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // loader: four input rows per call, (row, pixel pair, 8-channel chunk) tasks: 4 x 20 x 4 = 320, two slots per thread.  Three register
+    // sets: a fetch stays in flight for two row blocks (one block's products are over in ~0.7 us, an HBM round trip takes 2 - 3), and the
+    // k + 3 rows a strip starts with are requested together.
+    bf16x8 xv[3][2][2];
+    auto fetch = [&](auto set, int rb) {
+        constexpr int S = decltype(set)::value;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int t = tid + sl * 256;
+            if (t < 320) {
+                const int cq = t & 3, pp = (t >> 2) % 20, rr = t / 80, r = rb + rr;          // (40 of the 44 columns of a ring row are used)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int gx = x_t0 - OFF + 2 * pp + u;
+                    xv[S][sl][u] = (r >= 0 && r < H && gx >= 0 && gx < W) ? *(const bf16x8*)(ximg + ((int64_t)r * W + gx) * C + cq * 8) : z8;
+                }
+            }
+        }
+    };
+    auto stash = [&](auto set, int rb) {
+        constexpr int S = decltype(set)::value;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int t = tid + sl * 256;
+            if (t < 320) {
+                const int cq = t & 3, pp = (t >> 2) % 20, rr = t / 80, slot = (rb + rr + 64) & (RING - 1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    bf16x2 p2; p2[0] = xv[S][sl][0][e]; p2[1] = xv[S][sl][1][e];
+                    *(bf16x2*)(Xp + (cq * 8 + e) * XPS + slot * XW + 2 * pp) = p2;
+                }
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> S0; typedef std::integral_constant<int, 1> S1; typedef std::integral_constant<int, 2> S2;
+
+    // product roles: wave = (column half q: 16 columns, channel half h: 16 channels); lane = (channel blk, i / j)
+    const int h = wave & 1, q = wave >> 1, blk = lane >> 2, ij = lane & 3, ch = h * 16 + blk;
+    short4v Bw[K][NG];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            union { bf16 e[4]; short4v v; } t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int kx = 4 * g + k - ij - D0;
+                t.e[k] = (kx >= 0 && kx < K) ? (bf16)w[(int64_t)(ky * K + kx) * C + cbase + ch] : (bf16)0.f;
+            }
+            Bw[ky][g] = t.v;
+        }
+    const float bch = bias ? bias[cbase + ch] : 0.f;
+    const bf16* xa = Xp + ch * XPS + q * 16;
+    float* yw = Yp + ch * YPS + q * 16 + ij;
+
+    // rows y0 - P .. y0 + 3 + (K - 1 - P) before the first block: G0 groups of four, requested together
+    constexpr int G0 = (K + 3 + 3) / 4;
+    const int r_first = y0 - P;
+    fetch(S0{}, r_first); fetch(S1{}, r_first + 4);
+    if (G0 > 2) fetch(S2{}, r_first + 8);
+    stash(S0{}, r_first); stash(S1{}, r_first + 4);
+    if (G0 > 2) stash(S2{}, r_first + 8);
+    // block s (output rows y0 + 4 s ..) needs row group G0 + s - 1 on top of its predecessor's; group of block s + 1 sits in set (s + 1) & 1
+    auto rows_of = [&](int sblk) { return r_first + 4 * (G0 + sblk - 1); };
+    const int nblk = (y1 - y0 + 3) / 4;
+    if (nblk > 1) fetch(S1{}, rows_of(1));
+    if (nblk > 2) fetch(S0{}, rows_of(2));
+    auto block = [&](auto set, int sblk) {             // `set` holds the rows of block sblk + 1
+        const int yb = y0 + 4 * sblk;
+        __syncthreads();                               // the ring holds this block's rows; the previous block's outputs have left Yp
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+            floatx4 D = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const bf16* row = xa + ((yb + ij + ky - P + 64) & (RING - 1)) * XW + cg * 4;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) D = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(*(const short4v*)(row + 4 * g), Bw[ky][g], D, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yw[i * TC + cg * 4] = apply_act(D[i] + bch, act);
+        }
+        __syncthreads();
+        // the ring first (its fetch was issued two blocks ago), then the next fetch into the freed set, then this block's stores
+        if (sblk + 1 < nblk) stash(set, rows_of(sblk + 1));
+        if (sblk + 3 < nblk) fetch(set, rows_of(sblk + 3));
+        {   // channels-last stores: (row, pixel pair, chunk) = 4 x 16 x 4 = 256 tasks
+            const int cq = tid & 3, pp = (tid >> 2) & 15, i = tid >> 6;
+            const int oy = yb + i, gx = x_t0 + 2 * pp;
+            if (oy < y1 && gx < W) {
+                float v0[8], v1[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const floatx2 t = *(const floatx2*)(Yp + (cq * 8 + e) * YPS + i * TC + 2 * pp); v0[e] = t[0]; v1[e] = t[1]; }
+                const int64_t o = (((int64_t)b * H + oy) * W + gx) * C + cbase + cq * 8;
+                const bool two = gx + 1 < W;
+                if (res) {
+                    const bf16x8 r0 = *(const bf16x8*)(res + o), r1 = two ? *(const bf16x8*)(res + o + C) : z8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v0[e] += (float)r0[e]; v1[e] += (float)r1[e]; }
+                }
+                bf16x8 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o0[e] = (bf16)v0[e]; o1[e] = (bf16)v1[e]; }
+                *(bf16x8*)(y + o) = o0;
+                if (two) *(bf16x8*)(y + o + C) = o1;
+            }
+        }
+    };
+    for (int sblk = 0; sblk < nblk; sblk += 2) {
+        block(S1{}, sblk);
+        if (sblk + 1 < nblk) block(S0{}, sblk + 1);
     }
 }
 
@@ -449,6 +602,27 @@ static int dwconvk_fwd_impl(int dtype, const void* x, const float* wkkc, const f
     SS_CHECK((int64_t)(Ho - 1) * stride - pad_top < H && (int64_t)(Wo - 1) * stride - pad_left < W, "ss_dwconvk_fwd: output larger than the padded input");
     const int64_t total = (int64_t)B * Ho * Wo * (C / 8);
     const int blocks = (int)(cdiv(total, 256) < 32768 ? cdiv(total, 256) : 32768);
+    // SS_DWK_FWD=mfma: the 4x4x4-MFMA forward below instead of the vector-ALU tile kernel.  Measured on the four DNet maps (k = 7, B = 16) the two
+    // are level (234 / 160 / 89 / 48 us against 262 / 147 / 70 / 57 us, 2.08 against 2.05 ms over the step), so the tile kernel, which also
+    // serves fp32 and asymmetric padding, stays the default; the variable is read per call so that the tests cover both.
+    const char* fwd_env = getenv("SS_DWK_FWD");
+    const bool fwd_mfma = fwd_env && fwd_env[0] == 'm';
+    if (fwd_mfma && dtype == SS_BF16 && stride == 1 && C % 32 == 0 && (k == 3 || k == 5 || k == 7) && pad_top == k / 2 && pad_left == k / 2 && Ho == H &&
+        Wo == W && act >= 0 && act <= 3) {
+        const int tiles_x = (int)cdiv(W, 32), groups = C / 32;
+        int SR = 64;
+        while (SR > 32 && (int64_t)B * tiles_x * cdiv(H, SR) * groups < 1024) SR /= 2;     // (k - 1 halo rows per strip: no strips under 32 rows)
+        const int nsy = (int)cdiv(H, SR);
+        const int64_t wgs = (int64_t)B * tiles_x * nsy;
+        if (cdiv(wgs, 8) * 8 * groups < (1LL << 31)) {
+            dim3 grid((unsigned)(cdiv(wgs, 8) * 8 * groups));
+            if (k == 3) hipLaunchKernelGGL((dwk_fwd_mfma_kernel<3>), grid, dim3(256), 0, stream, (const bf16*)x, wkkc, bias, (const bf16*)res, (bf16*)y, H, W, C, act, tiles_x, nsy, SR, (int)wgs);
+            else if (k == 5) hipLaunchKernelGGL((dwk_fwd_mfma_kernel<5>), grid, dim3(256), 0, stream, (const bf16*)x, wkkc, bias, (const bf16*)res, (bf16*)y, H, W, C, act, tiles_x, nsy, SR, (int)wgs);
+            else hipLaunchKernelGGL((dwk_fwd_mfma_kernel<7>), grid, dim3(256), 0, stream, (const bf16*)x, wkkc, bias, (const bf16*)res, (bf16*)y, H, W, C, act, tiles_x, nsy, SR, (int)wgs);
+            SS_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (stride == 1 && C % 32 == 0 && (k == 3 || k == 5 || k == 7) && act >= 0 && act <= 3 && (!bias || aligned16(bias)) &&
         (int64_t)B * cdiv(Wo, 64) * cdiv(Ho, 8) < (1LL << 31)) {
         SS_DISPATCH(dtype, {
@@ -493,10 +667,10 @@ extern "C" int ss_dwconvk_wgrad(int dtype, const void* g, const void* x, float* 
         const int nsy = (int)cdiv(H, SR);
         const int64_t strips = (int64_t)B * tiles_x * nsy;
         if (strips * 2 <= SS_COLRED_MAX_BLOCKS && SR < (1 << 20)) {
-            dim3 grid((unsigned)strips, (unsigned)(C / 32));
-            if (k == 3) hipLaunchKernelGGL((dwk_wgrad_mfma_kernel<3>), grid, dim3(256), 0, stream, (const bf16*)g, (const bf16*)x, workspace, H, W, C, tiles_x, nsy, SR);
-            else if (k == 5) hipLaunchKernelGGL((dwk_wgrad_mfma_kernel<5>), grid, dim3(256), 0, stream, (const bf16*)g, (const bf16*)x, workspace, H, W, C, tiles_x, nsy, SR);
-            else hipLaunchKernelGGL((dwk_wgrad_mfma_kernel<7>), grid, dim3(256), 0, stream, (const bf16*)g, (const bf16*)x, workspace, H, W, C, tiles_x, nsy, SR);
+            dim3 grid((unsigned)(cdiv(strips, 8) * 8 * (C / 32)));
+            if (k == 3) hipLaunchKernelGGL((dwk_wgrad_mfma_kernel<3>), grid, dim3(256), 0, stream, (const bf16*)g, (const bf16*)x, workspace, H, W, C, tiles_x, nsy, SR, (int)strips);
+            else if (k == 5) hipLaunchKernelGGL((dwk_wgrad_mfma_kernel<5>), grid, dim3(256), 0, stream, (const bf16*)g, (const bf16*)x, workspace, H, W, C, tiles_x, nsy, SR, (int)strips);
+            else hipLaunchKernelGGL((dwk_wgrad_mfma_kernel<7>), grid, dim3(256), 0, stream, (const bf16*)g, (const bf16*)x, workspace, H, W, C, tiles_x, nsy, SR, (int)strips);
             SS_LAUNCH_CHECK();
             hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(rows * C, 8), 1), dim3(256), 0, stream, workspace, (int)(strips * 2), rows * C, 1.f, dw_db, 0);
             SS_LAUNCH_CHECK();

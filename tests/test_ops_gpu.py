@@ -693,10 +693,14 @@ def test_droppath_keep_matches_torch_ops(ops, dtype):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('k,C,H,W,pt,pl,act', [(7, 96, 19, 70, 3, 3, 0), (5, 32, 9, 130, 2, 2, 2), (3, 64, 8, 64, 1, 1, 3), (7, 32, 5, 3, 3, 3, 1),
-                                                (5, 32, 12, 66, 1, 3, 0), (7, 40, 10, 20, 3, 3, 0)])
-def test_dwconvk_stride1_tiled_and_fallback(ops, dtype, k, C, H, W, pt, pl, act):
-    """depthwise k x k, stride 1: the LDS-tiled kernel (C % 32 == 0; ragged tiles, asymmetric padding, fused activation) and the
-    per-pixel fallback (C = 40) against F.conv2d on explicitly padded input."""
+                                                (5, 32, 12, 66, 1, 3, 0), (7, 40, 10, 20, 3, 3, 0), (7, 192, 150, 33, 3, 3, 0), (3, 96, 70, 129, 1, 1, 2),
+                                                (5, 160, 3, 1, 2, 2, 3)])
+@pytest.mark.parametrize('path', ['tile', 'mfma'])
+def test_dwconvk_stride1_tiled_and_fallback(ops, dtype, k, C, H, W, pt, pl, act, path, monkeypatch):
+    """depthwise k x k, stride 1: the LDS-tiled kernel (C % 32 == 0; ragged tiles, asymmetric padding, fused activation), the per-pixel
+    fallback (C = 40) and, with SS_DWK_FWD=mfma (read per call), the 4x4x4-MFMA kernel (bf16, centred padding) against F.conv2d on
+    explicitly padded input."""
+    monkeypatch.setenv('SS_DWK_FWD', path)
     B = 2
     x, w, b = rnd(B, C, H, W), rnd(C, 1, k, k, seed=1) / k, rnd(C, seed=2)
     Ho, Wo = H + 2 * pt - k + 1 if pt * 2 >= k - 1 else H, W
@@ -789,9 +793,11 @@ def test_gemm_nt_gelu2_equals_gemm_then_gelu(dtype, shape):
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize('geom', [(2, 24, 40, 64, 7, 1), (1, 9, 70, 32, 3, 1), (2, 16, 16, 24, 5, 2)])
-def test_dwconvk_fwd_with_residual(dtype, geom):
-    """y = dw(x) + res in one kernel (tiled and generic paths) vs the two-step result computed in fp32."""
+@pytest.mark.parametrize('path', ['tile', 'mfma'])
+def test_dwconvk_fwd_with_residual(dtype, geom, path, monkeypatch):
+    """y = dw(x) + res in one kernel (tiled, MFMA and generic paths) vs the two-step result computed in fp32."""
     from semseg_amd import ops
+    monkeypatch.setenv('SS_DWK_FWD', path)
     B, H, W, C, k, s = geom
     g = torch.Generator().manual_seed(C + k)
     x = torch.randn((B * H * W, C), generator=g).to(dtype).cuda()
