@@ -254,18 +254,6 @@ int ss_wide_nt_launch(FastGemm p, hipStream_t st) {
     return 0;
 }
 
-// LDS-DMA by hand for the persistent kernel.  hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of any LDS access once an
-// LDS-DMA builtin is in flight (it cannot tell the stages apart), which would make every k-iteration wait for the prefetch it has
-// just issued; instructions it does not see are waited for by the kernel itself.  M0 (the LDS destination) is written right before
-// each use and nothing else in the kernel reads it.
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(lds_void*)p; }
-__device__ __forceinline__ void dma_b128(const void* g, unsigned lds_uniform) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(lds_uniform) : "memory");
-}
-__device__ __forceinline__ void dma_b32(const void* g, unsigned lds_uniform) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_uniform) : "memory");
-}
-
 // Persistent form: one workgroup per CU walks a run of tiles of its XCD.  The last k-iteration of a tile already issues the first
 // k-tile of the NEXT tile into the free stage, and the epilogue is per wave through 4 KiB of LDS of its own (nt_epilogue_wave), so
 // a tile's drain (bias / activation / residual, 128 KiB of stores) overlaps the next tile's fill instead of an idle chip; no

@@ -13,8 +13,6 @@
 #include "common.h"
 #include "gemm_fast.h"
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void glb_void;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 __device__ __forceinline__ int xcd_remap_tnb(int bid, int nwg) {
@@ -22,12 +20,29 @@ __device__ __forceinline__ int xcd_remap_tnb(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// Top of k-iteration kt in a ring of S stages: this wave's fills of tile kt have landed (fills complete in order; the `ahead` newer
+// tiles, PER fills each, may still be on their way), then the workgroup barrier: every wave's part of tile kt is in LDS and nobody still
+// reads the stage about to be refilled.
+template <int PER>
+__device__ __forceinline__ void tn_wait_barrier(int ahead) {
+    static_assert(3 * PER <= 63, "vmcnt is a 6-bit field");
+    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(3 * PER) : "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 * PER) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// BK rows per stage, S stages (S - 1 k-tiles in flight).  Both operands of a weight gradient are streams from HBM (every k-tile is new
+// data, ~2 us away), and a k-tile of 64 rows is multiplied in 0.85 us: with one tile in flight the k-iteration was that round trip.
+template <int BK, int S>
 __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(FastGemm p) {
-    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int BM = 256, BN = 256;
     constexpr int PITCH = BM * 2;                      // 512-byte rows
-    constexpr int IMG = BK * PITCH;                    // one operand image: 32 KiB
+    constexpr int IMG = BK * PITCH;                    // one operand image
     constexpr int STAGE = 2 * IMG;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    constexpr int NP = BK / 16;                        // 1 KiB fill pieces per wave and operand
+    static_assert(S >= 2 && S <= 5 && S * STAGE <= 160 * 1024 && BK % 16 == 0, "ring must fit the LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[S * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -40,26 +55,27 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(FastGemm p) {
     const int64_t kend = kbeg + p.k_per_split < p.K ? kbeg + p.k_per_split : p.K;
     const int nk = (int)((kend - kbeg) / BK);
 
-    // LDS-DMA sources: piece q = wave*4 + i covers rows 2q, 2q+1 of a stage image; this lane fills physical slot (lane & 31) of
+    // LDS-DMA sources: piece q = wave*NP + i covers rows 2q, 2q+1 of a stage image; this lane fills physical slot (lane & 31) of
     // row 2q + (lane >> 5), which holds logical slot (lane & 31) ^ ((row & 3) << 2)
-    const bf16* pa[4]; const bf16* pb[4];
+    const bf16* pa[NP]; const bf16* pb[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 2 + (lane >> 5);
+    for (int i = 0; i < NP; ++i) {
+        const int row = (wave * NP + i) * 2 + (lane >> 5);
         const int ls = (lane & 31) ^ ((row & 3) << 2);
         const int ca = m0 + ls * 8 < p.M ? m0 + ls * 8 : m0;
         const int cb = n0 + ls * 8 < p.N ? n0 + ls * 8 : n0;
         pa[i] = p.A + (kbeg + row) * p.lda + ca;
         pb[i] = p.B + (kbeg + row) * p.ldb + cb;
     }
-    auto issue = [&](int kt) {
-        char* st = smem + (kt & 1) * STAGE + wave * 4096;
+    // fills by hand (dma_b128, gemm_fast.h): with the builtin the compiler made the transpose reads of tile kt wait for the fill of tile
+    // kt + 1 issued just before them -- fill and products took turns (2.4 us per k-tile for 0.85 us of matrix work)
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * NP * 1024);
+    auto issue = [&](int kt, int stage) {
+        const unsigned st = lds0 + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void*)(pa[i] + (int64_t)kt * BK * p.lda), (lds_void*)(st + i * 1024), 16, 0, 0);
+        for (int i = 0; i < NP; ++i) dma_b128(pa[i] + (int64_t)kt * BK * p.lda, st + i * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void*)(pb[i] + (int64_t)kt * BK * p.ldb), (lds_void*)(st + IMG + i * 1024), 16, 0, 0);
+        for (int i = 0; i < NP; ++i) dma_b128(pb[i] + (int64_t)kt * BK * p.ldb, st + IMG + i * 1024);
     };
 
     floatx16 acc[2][4];
@@ -86,19 +102,35 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(FastGemm p) {
     };
 
     const bool do_cs = p.colsum_ws && n0 == 0;
-    float cs = 0.f, keep_mul = p.rowscale ? 0.f : 1.f;
-    if (nk > 0) issue(0);
+    float cs = 0.f;
+    // DropPath row keep (see gemm_tn_bf16_kernel): k-tiles of dropped samples are skipped, the kept ones share one multiplier.  The flags
+    // of the samples this split touches (at most 64: ss_big_tn_ok) are read ONCE into a mask -- a load per k-tile would queue behind the
+    // fills and its wait would be a wait for them
+    unsigned long long keep_mask = ~0ull;
+    float keep_mul = 1.f;
+    int srow = 0, sidx = 0;
+    if (p.rowscale) {
+        const int64_t s0 = kbeg / p.rows_per_scale;
+        const int64_t nsmp = nk > 0 ? (kend - 1) / p.rows_per_scale - s0 + 1 : 0;
+        const float v = lane < nsmp ? p.rowscale[s0 + lane] : 0.f;
+        keep_mask = __builtin_amdgcn_ballot_w64(v != 0.f);
+        keep_mul = group_max(v, 64);
+        srow = (int)(kbeg - s0 * p.rows_per_scale);
+    }
+    for (int t = 0; t < S - 1 && t < nk; ++t) issue(t, t);
+    int cur = 0, nxt = S - 1;                          // stages of tile kt and of tile kt + S - 1
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                               // tile kt has landed; nobody still reads the other stage
-        if (kt + 1 < nk) issue(kt + 1);
-        const char* As = smem + (kt & 1) * STAGE;
+        tn_wait_barrier<2 * NP>(min(S - 2, nk - 1 - kt));
+        if (kt + S - 1 < nk) issue(kt + S - 1, nxt);
+        const char* As = smem + cur * STAGE;
         const char* Bs = As + IMG;
-        // row keep (see gemm_tn_bf16_kernel): k-tiles of dropped samples are skipped, the kept ones share one multiplier
-        const float kv = p.rowscale ? p.rowscale[(kbeg + (int64_t)kt * BK) / p.rows_per_scale] : 1.f;
-        if (kv != 0.f) keep_mul = kv;
+        cur = cur + 1 == S ? 0 : cur + 1;
+        nxt = nxt + 1 == S ? 0 : nxt + 1;
+        const bool kept = (keep_mask >> sidx) & 1;
+        srow += BK;
+        if (p.rowscale && srow >= p.rows_per_scale) { srow -= (int)p.rows_per_scale; ++sidx; }
 #pragma unroll
-        for (int ks = 0; ks < (kv != 0.f ? BK / 16 : 0); ++ks) {
+        for (int ks = 0; ks < (kept ? BK / 16 : 0); ++ks) {
             bf16x8 fa[2], fb[4];
 #pragma unroll
             for (int a = 0; a < 2; ++a) fa[a] = trfrag(As, ks, wm * 64 + a * 32);
@@ -146,14 +178,18 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(FastGemm p) {
 // (waves 2 x 4, 160 x 64 each).  Operand rows in LDS are BM*2 / BN*2 bytes (512 / 640: multiples of 128, so the rows of a transpose
 // block share their banks); 16-byte slot s of row r lives at s ^ ((r & 1) << 2) -- odd rows shifted by 64 bytes inside their 128-byte
 // block, which is what the four-row transpose read needs -- applied to the fill's source address and to the fragment reads.
-template <int TA, int TB, int WM, int WN>
-__global__ __launch_bounds__(512) void gemm_tn_bf16_wide_kernel(FastGemm p) {
-    constexpr int BM = WM * TA * 32, BN = WN * TB * 32, BK = 64;
+// The thin weight gradients of the Mix-FFN (MiT stages 1-2: 64 .. 512 x 64 .. 512 outputs over 2^18 .. 2^20 rows) use it with ONE tile =
+// the whole output, so every operand row is read once and a workgroup's fill in flight is 32 .. 80 KiB (two workgroups per CU where two
+// pairs of stages fit): these products are HBM streams, and the 128-tile kernel kept 24 .. 32 KiB per workgroup in flight through registers.
+template <int TA, int TB, int WM, int WN, int BK = 64, int S = 2>
+__global__ __launch_bounds__(512, (WM * TA + WN * TB) * 32 * BK * 2 * S <= 80 * 1024 ? 2 : 1) void gemm_tn_bf16_wide_kernel(FastGemm p) {
+    constexpr int BM = WM * TA * 32, BN = WN * TB * 32;
     constexpr int PA = BM * 2, PB = BN * 2;            // row pitches (bytes)
     constexpr int IMGA = BK * PA, IMGB = BK * PB, STAGE = IMGA + IMGB;
     constexpr int QA = IMGA / 1024 / 8, QB = IMGB / 1024 / 8;          // 1 KiB fill pieces per wave
     static_assert(WM * WN == 8 && IMGA % 8192 == 0 && IMGB % 8192 == 0, "eight waves, whole pieces per wave");
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    static_assert(S >= 2 && S <= 5 && S * STAGE <= 160 * 1024 && BK % 16 == 0, "ring must fit the LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[S * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -178,14 +214,13 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_wide_kernel(FastGemm p) {
         const int cb = n0 + ls * 8 < p.N ? n0 + ls * 8 : n0;
         pb[i] = p.B + (kbeg + row) * p.ldb + cb;
     }
-    auto issue = [&](int kt) {
-        char* st = smem + (kt & 1) * STAGE;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    auto issue = [&](int kt, int stage) {              // by hand, see gemm_tn_bf16_256_kernel
+        const unsigned st = lds0 + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < QA; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void*)(pa[i] + (int64_t)kt * BK * p.lda), (lds_void*)(st + (wave * QA + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < QA; ++i) dma_b128(pa[i] + (int64_t)kt * BK * p.lda, st + (wave * QA + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < QB; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void*)(pb[i] + (int64_t)kt * BK * p.ldb), (lds_void*)(st + IMGA + (wave * QB + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < QB; ++i) dma_b128(pb[i] + (int64_t)kt * BK * p.ldb, st + IMGA + (wave * QB + i) * 1024);
     };
 
     floatx16 acc[TA][TB];
@@ -213,18 +248,34 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_wide_kernel(FastGemm p) {
     float cs[TA];
 #pragma unroll
     for (int a = 0; a < TA; ++a) cs[a] = 0.f;
-    float keep_mul = p.rowscale ? 0.f : 1.f;
-    if (nk > 0) issue(0);
+    // DropPath row keep (see gemm_tn_bf16_kernel): k-tiles of dropped samples are skipped, the kept ones share one multiplier.  The flags
+    // of the samples this split touches (at most 64: ss_big_tn_ok) are read ONCE into a mask -- a load per k-tile would queue behind the
+    // fills and its wait would be a wait for them
+    unsigned long long keep_mask = ~0ull;
+    float keep_mul = 1.f;
+    int srow = 0, sidx = 0;
+    if (p.rowscale) {
+        const int64_t s0 = kbeg / p.rows_per_scale;
+        const int64_t nsmp = nk > 0 ? (kend - 1) / p.rows_per_scale - s0 + 1 : 0;
+        const float v = lane < nsmp ? p.rowscale[s0 + lane] : 0.f;
+        keep_mask = __builtin_amdgcn_ballot_w64(v != 0.f);
+        keep_mul = group_max(v, 64);
+        srow = (int)(kbeg - s0 * p.rows_per_scale);
+    }
+    for (int t = 0; t < S - 1 && t < nk; ++t) issue(t, t);
+    int cur = 0, nxt = S - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) issue(kt + 1);
-        const char* As = smem + (kt & 1) * STAGE;
+        tn_wait_barrier<QA + QB>(min(S - 2, nk - 1 - kt));
+        if (kt + S - 1 < nk) issue(kt + S - 1, nxt);
+        const char* As = smem + cur * STAGE;
         const char* Bs = As + IMGA;
-        const float kv = p.rowscale ? p.rowscale[(kbeg + (int64_t)kt * BK) / p.rows_per_scale] : 1.f;
-        if (kv != 0.f) keep_mul = kv;
+        cur = cur + 1 == S ? 0 : cur + 1;
+        nxt = nxt + 1 == S ? 0 : nxt + 1;
+        const bool kept = (keep_mask >> sidx) & 1;
+        srow += BK;
+        if (p.rowscale && srow >= p.rows_per_scale) { srow -= (int)p.rows_per_scale; ++sidx; }
 #pragma unroll
-        for (int ks = 0; ks < (kv != 0.f ? BK / 16 : 0); ++ks) {
+        for (int ks = 0; ks < (kept ? BK / 16 : 0); ++ks) {
             bf16x8 fa[TA], fb[TB];
 #pragma unroll
             for (int a = 0; a < TA; ++a) fa[a] = trfrag(As, PA, ks, wm * TA * 32 + a * 32);
@@ -274,7 +325,13 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_wide_kernel(FastGemm p) {
 // of 256) and the other one suits 256 / 320 rows.  0 = none (the 128-tile kernel takes the shape).
 static int tn_tile_shape(int64_t M, int64_t N, int* bm, int* bn) {
     auto fits = [](int64_t x, int t) { return x >= t && (double)(cdiv(x, t) * t) <= 1.25 * (double)x; };
-    if (M < 256 || N < 256 || M % 8 || N % 8) return 0;
+    if (M % 8 || N % 8) return 0;
+    // one tile = the whole output (thin shapes; at most 25 % of a side is padding)
+    auto whole = [](int64_t x, int t) { return x <= t && 5 * x >= 4 * t; };
+    static const int thin[5][2] = {{512, 128}, {128, 512}, {256, 64}, {64, 256}, {128, 128}};
+    for (int i = 0; i < 5; ++i)
+        if (whole(M, thin[i][0]) && whole(N, thin[i][1])) { *bm = thin[i][0]; *bn = thin[i][1]; return 4 + i; }
+    if (M < 256 || N < 256) return 0;
     if ((double)(cdiv(M, 256) * 256) * (double)(cdiv(N, 256) * 256) <= 1.5 * (double)M * (double)N) { *bm = 256; *bn = 256; return 1; }
     if (N % 320 == 0 && fits(M, 256)) { *bm = 256; *bn = 320; return 2; }
     if (M % 320 == 0 && fits(N, 256)) { *bm = 320; *bn = 256; return 3; }
@@ -285,9 +342,11 @@ static int tn_tile_shape(int64_t M, int64_t N, int* bm, int* bn) {
 // output alone has more tiles), splits of whole k-tiles.  False when the shape does not suit the tile.
 bool ss_big_tn_plan(int64_t M, int64_t N, int64_t R, int* nsplit, int64_t* rps) {
     int bm, bn;
-    if (R % 64 || R < 4096 || !tn_tile_shape(M, N, &bm, &bn)) return false;
+    const int shape = R % 64 || R < 4096 ? 0 : tn_tile_shape(M, N, &bm, &bn);
+    if (!shape) return false;
     const int64_t tiles = cdiv(M, bm) * cdiv(N, bn);
-    int64_t s = tiles >= 256 ? 1 : 256 / tiles;
+    const int64_t slots = (bm + bn) <= 320 ? 512 : 256;        // two workgroups per CU where their LDS allows (256 x 64, 64 x 256, 128 x 128)
+    int64_t s = tiles >= slots ? 1 : slots / tiles;
     const int64_t maxs = R / (8 * 64);                 // >= 8 k-tiles per split
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
@@ -302,7 +361,15 @@ bool ss_big_tn_ok(const FastGemm& p, int nsplit) {
     int bm, bn;
     if (!aligned16(p.A) || !aligned16(p.B) || p.lda % 8 || p.ldb % 8 || !tn_tile_shape(p.M, p.N, &bm, &bn)) return false;
     if (p.K % 64 || p.k_per_split % 64) return false;
+    if (p.rowscale && (p.rows_per_scale % 64 || p.rows_per_scale >= (1LL << 31) || cdiv(p.k_per_split, p.rows_per_scale) + 1 > 64)) return false;   // the keep mask
     return cdiv(p.M, bm) * cdiv(p.N, bn) * nsplit < (1LL << 30);
+}
+
+// SS_GEMM_TN_RING=0: two stages of 64 rows instead of five of 32 in the 256 x 256 kernel (A/B runs)
+static int tn_ring_mode() {
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("SS_GEMM_TN_RING"); m = e && e[0] == '0' ? 0 : 1; }
+    return m;
 }
 
 int ss_big_tn_launch(FastGemm p, int nsplit, hipStream_t st) {
@@ -313,7 +380,13 @@ int ss_big_tn_launch(FastGemm p, int nsplit, hipStream_t st) {
     const dim3 grid((unsigned)(p.ntiles * nsplit));
     if (shape == 2) hipLaunchKernelGGL((gemm_tn_bf16_wide_kernel<2, 5, 4, 2>), grid, dim3(512), 0, st, p);
     else if (shape == 3) hipLaunchKernelGGL((gemm_tn_bf16_wide_kernel<5, 2, 2, 4>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL(gemm_tn_bf16_256_kernel, grid, dim3(512), 0, st, p);
+    else if (shape == 4) hipLaunchKernelGGL((gemm_tn_bf16_wide_kernel<4, 2, 4, 2, 32, 4>), grid, dim3(512), 0, st, p);      // 512 x 128
+    else if (shape == 5) hipLaunchKernelGGL((gemm_tn_bf16_wide_kernel<2, 4, 2, 4, 32, 4>), grid, dim3(512), 0, st, p);      // 128 x 512
+    else if (shape == 6) hipLaunchKernelGGL((gemm_tn_bf16_wide_kernel<2, 1, 4, 2>), grid, dim3(512), 0, st, p);      // 256 x 64
+    else if (shape == 7) hipLaunchKernelGGL((gemm_tn_bf16_wide_kernel<1, 2, 2, 4>), grid, dim3(512), 0, st, p);      // 64 x 256
+    else if (shape == 8) hipLaunchKernelGGL((gemm_tn_bf16_wide_kernel<2, 1, 2, 4, 32, 4>), grid, dim3(512), 0, st, p);      // 128 x 128
+    else if (tn_ring_mode() == 0) hipLaunchKernelGGL((gemm_tn_bf16_256_kernel<64, 2>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gemm_tn_bf16_256_kernel<32, 5>), grid, dim3(512), 0, st, p);
     SS_LAUNCH_CHECK();
     return 0;
 }

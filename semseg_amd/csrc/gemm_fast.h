@@ -251,3 +251,16 @@ __device__ __forceinline__ void nt_epilogue_wave(floatx16 (&acc)[TA][TB], const 
     }
 #undef SS_EPW
 }
+
+// LDS-DMA by hand.  hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of an LDS access it cannot prove disjoint from an LDS-DMA
+// builtin in flight (always so for the transpose-read intrinsic, and for plain reads of the same array), which makes every k-iteration
+// wait for the prefetch it has just issued; instructions it does not see are waited for by the kernel itself (s_waitcnt vmcnt(N) before
+// the barrier that hands a stage over).  M0 (the LDS destination) is written right before each use and nothing else in these kernels reads it.
+typedef __attribute__((address_space(3))) void ss_lds_void;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(ss_lds_void*)p; }
+__device__ __forceinline__ void dma_b128(const void* g, unsigned lds_uniform) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(lds_uniform) : "memory");
+}
+__device__ __forceinline__ void dma_b32(const void* g, unsigned lds_uniform) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_uniform) : "memory");
+}

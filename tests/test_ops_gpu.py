@@ -92,7 +92,9 @@ def test_gemm_nt_bf16_fast_path(ops, M, N, K):
 @pytest.mark.parametrize('R,M,N', [(5000, 64, 64), (4097, 320, 1280), (9000, 512, 48 + 512), (1024, 128, 2048), (70, 8, 16), (3000, 1152, 320),
                                    (70001, 6, 512), (333, 3, 1032),
                                    (8192, 512, 256), (4096, 384, 512), (12288, 256, 328), (16384, 520, 768),     # 256-tile kernel, ragged tiles
-                                   (8192, 1280, 320), (8192, 320, 1280), (4096, 328, 640), (12288, 640, 264)])   # 256 x 320 / 320 x 256 tiles
+                                   (8192, 1280, 320), (8192, 320, 1280), (4096, 328, 640), (12288, 640, 264),    # 256 x 320 / 320 x 256 tiles
+                                   (8192, 512, 128), (16384, 128, 512), (65536, 256, 64), (32768, 64, 256), (8192, 128, 128),
+                                   (8192, 448, 104), (4096, 56, 208)])                                           # one tile = the whole output
 def test_gemm_tn_bf16_fast_path(ops, R, M, N):
     dtype = torch.bfloat16
     a, b = rnd(R, M), rnd(R, N, seed=1)
@@ -107,7 +109,8 @@ def test_gemm_tn_bf16_fast_path(ops, R, M, N):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('R,M,N', [(5000, 64, 64), (70001, 320, 136), (9000, 512, 48 + 512), (300, 8, 16), (4097, 6, 512), (100000, 1280, 320),
-                                   (8192, 512, 512), (4096, 328, 256), (65536, 1280, 320), (8192, 320, 1280), (8192, 640, 1000)])
+                                   (8192, 512, 512), (4096, 328, 256), (65536, 1280, 320), (8192, 320, 1280), (8192, 640, 1000),
+                                   (65536, 256, 64), (16384, 512, 128), (8192, 104, 448), (8192, 64, 256), (4096, 128, 128)])
 def test_gemm_tn_with_bias_gradient(ops, dtype, R, M, N):
     """ss_gemm_tn_colsum: dW = dY^T X and db = column sums of dY from one pass (fused in the bf16 MFMA kernel, a second launch on
     the other paths); must agree with the two separate entry points."""
@@ -121,7 +124,8 @@ def test_gemm_tn_with_bias_gradient(ops, dtype, R, M, N):
 
 
 @pytest.mark.parametrize('R,M,N,rpk', [(4096, 64, 256, 1024), (8192, 320, 1280, 1024), (16384, 512, 2048, 1024), (65536, 128, 128, 4096),
-                                       (1024, 64, 64, 64), (12288, 512, 512, 4096), (8192, 1280, 320, 1024)])
+                                       (1024, 64, 64, 64), (12288, 512, 512, 4096), (8192, 1280, 320, 1024),
+                                       (131072, 512, 128, 8192), (65536, 256, 64, 1024), (16384, 128, 512, 256), (16384, 512, 512, 256)])
 def test_gemm_tn_droppath_keep(ops, R, M, N, rpk):
     """ss_gemm_tn_colsum_keep: weight / bias gradient under DropPath (modules/helpers.py:9-24) from the unscaled gradient; equals the plain
     entry point on the row-scaled gradient up to the rounding of that scaled copy, and is exactly zero when every sample is dropped."""
