@@ -133,6 +133,35 @@ __device__ __forceinline__ void gelu_parts_v(const float (&x)[NE], float (&cdf)[
     DW_PIN_VALU();
 }
 
+// GELU'(u) by linear interpolation in a table kept in LDS (bf16 storage only): 1024 intervals of 1/64 over [-8, 8), entry = (value, step to
+// the next value).  Interpolation error <= h^2 / 8 * max|third derivative of GELU| = 2.5e-5, two orders below the rounding of the bf16
+// gradient the result is multiplied into; outside the range the derivative is 0 / 1 to 1e-14.  Six vector instructions and one
+// ds_read_b64 per value where the closed form (gelu_parts_v: reciprocal, exponential, five-term polynomial) takes twenty-one on a kernel
+// that is vector-ALU bound; the LDS pipe is idle next to it.  A NaN in u reads entry 0 (the index conversion maps it there) -- the
+// gradient it multiplies carries the NaN.
+#ifndef DWF_LUT
+#define DWF_LUT 1
+#endif
+constexpr int GELU_LUT_N = 1024;
+__device__ __forceinline__ void gelu_grad_lut_fill(float2* lut, int tid, int nthreads) {
+    for (int i = tid; i < GELU_LUT_N; i += nthreads) {
+        const float f0 = gelu_erf_grad((float)(i - GELU_LUT_N / 2) * (1.f / 64.f)), f1 = gelu_erf_grad((float)(i + 1 - GELU_LUT_N / 2) * (1.f / 64.f));
+        lut[i] = make_float2(f0, f1 - f0);
+    }
+}
+template <int NE>
+__device__ __forceinline__ void gelu_grad_lut(const float2* lut, const float (&u)[NE], float (&d)[NE]) {
+    float t[NE]; unsigned idx[NE]; float2 en[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) t[e] = __builtin_amdgcn_fmed3f(fmaf(u[e], 64.f, (float)(GELU_LUT_N / 2)), 0.f, (float)GELU_LUT_N - 0.004f);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) idx[e] = (unsigned)t[e];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) en[e] = lut[idx[e]];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) d[e] = fmaf(__builtin_amdgcn_fractf(t[e]), en[e].y, en[e].x);
+}
+
 // Row r of the strip reaches the window through a ring of 3 raw rows: its loads are issued three steps before the step that
 // converts it, so a wave's own arithmetic covers its own HBM latency (two waves per SIMD suffice).
 template <typename T, int NE, int ACT>
@@ -351,7 +380,10 @@ __global__ __launch_bounds__(256, OCC) void dwconv3_bwd_fused_kernel(const T* __
     typedef vecn<T, NE> V;
     __shared__ float shf[256 * NE > 2 * 256 * NE * (int)sizeof(T) / 4 ? 256 * NE : 2 * 256 * NE * (int)sizeof(T) / 4];
     V* gx = (V*)shf;                                        // [2][256] rows of g in flight between column neighbours
+    constexpr bool LUT = DWF_LUT && ACT == 1 && sizeof(T) == 2;
+    __shared__ float2 lut[LUT ? GELU_LUT_N : 1];
     const int tid = threadIdx.x, cl = tid % g.cpb, xs = tid / g.cpb;
+    if (LUT) { gelu_grad_lut_fill(lut, tid, 256); __syncthreads(); }
     const int chunk_raw = blockIdx.y * g.cpb + cl;
     const bool cok = chunk_raw < g.chunks;
     const int chunk = cok ? chunk_raw : g.chunks - 1, c = chunk * NE;
@@ -427,7 +459,8 @@ __global__ __launch_bounds__(256, OCC) void dwconv3_bwd_fused_kernel(const T* __
                 dring[i % 3] = raw_load<T, NE>(pd + (int64_t)(min(max(r + 3, 0), dlast) - rb) * rs);
                 V gv;
                 float dact[NE];
-                if (ACT == 1) {
+                if (LUT) gelu_grad_lut<NE>(lut, u, dact);
+                else if (ACT == 1) {
                     float cdf[NE], ez[NE];
                     gelu_parts_v<NE>(u, cdf, ez);
 #pragma unroll

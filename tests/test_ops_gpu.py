@@ -427,8 +427,9 @@ def test_dwconv3(ops, dtype, B, H, W, C):
     assert rel(dx2.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _gtol(dtype)
     assert rel(dwdb2[:9].t().reshape(C, 1, 3, 3), wr.grad) < _gtol(dtype)
     assert rel(dwdb2[9], br.grad) < _gtol(dtype)
-    if dtype == torch.bfloat16:                         # against the two-pass form: same rounded g, only the summation order differs
-        assert rel(dx2, dx) < 1e-2 and rel(dwdb2, dwdb) < 1e-3
+    if dtype == torch.bfloat16:     # against the two-pass form: the summation order differs, and the one-pass kernel interpolates GELU' in a
+        # table (2.5e-5 absolute), which moves an occasional g across a bf16 rounding boundary (32 terms per sum at the smallest shape)
+        assert rel(dx2, dx) < 1e-2 and rel(dwdb2, dwdb) < 3e-3
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
