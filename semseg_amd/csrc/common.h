@@ -94,8 +94,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Sum over aligned groups of `lanes` lanes (power of two <= 64), every lane receives it.  The first four steps are DPP operand
+// modifiers of the add itself (quad permutes, then the half-row and row mirrors: inside a group whose quads / halves already agree a
+// mirror is as good as an xor); __shfl_xor is a ds_bpermute_b32, an LDS-crossbar round trip per step.
+template <int CTRL> __device__ __forceinline__ float dpp_add_t(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float group_sum(float v, int lanes) {      // lanes: power of two <= 64
-    for (int o = lanes >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lanes >= 2) v = dpp_add_t<0xB1>(v);             // quad_perm [1, 0, 3, 2]
+    if (lanes >= 4) v = dpp_add_t<0x4E>(v);             // quad_perm [2, 3, 0, 1]
+    if (lanes >= 8) v = dpp_add_t<0x141>(v);            // row_half_mirror
+    if (lanes >= 16) v = dpp_add_t<0x140>(v);           // row_mirror
+    for (int o = 16; o < lanes; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 __device__ __forceinline__ float group_max(float v, int lanes) {
