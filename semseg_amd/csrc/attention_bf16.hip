@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* _
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+        mx = xor32_max(mx) * c;
         const float mn = fmaxf(m, mx);
         if (__builtin_amdgcn_ballot_w64(mn > m)) {          // some query's maximum moved: rescale (alpha = 1 for the others)
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void mit_attn_fwd_bf16_kernel(const bf16* _
         MFMA_PRIO_DOWN();
         __syncthreads();
     }
-    l += __shfl_xor(l, 32, 64);
+    l = xor32_sum(l);
     if (h == 0 && q0 + j < N) lse[(int64_t)(b * heads + hd) * Np + q0 + j] = m + log2f(l);
     if (q0 < N)
         store_rows_bf16<D>(oacc, 1.f / l, smem + wave * 32 * (D * 2 + 16), o + ((int64_t)b * N + q0) * C + hd * D, C, N - q0);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void mit_attn_bwd_dq_bf16_kernel(const bf16
 #pragma unroll
         for (int e = 0; e < 8; ++e) dl = fmaf((float)dof[s][e], (float)of[e], dl);
     }
-    dl += __shfl_xor(dl, 32, 64);
+    dl = xor32_sum(dl);
     if (h == 0 && q0 + j < N) delta[(int64_t)(b * heads + hd) * Np + q0 + j] = dl;
     // The row constants ride in as the INITIAL accumulators of the two score products (lane = query, so one value per lane):
     // S' = K.Q^T - lse / c and dP' = V.dO^T - delta leave their MFMA chains ready, P = 2^(S' c) needs no subtraction, dS' = P dP'

@@ -113,6 +113,13 @@ __device__ __forceinline__ float group_max(float v, int lanes) {
     return v;
 }
 
+// Exchange between the two 32-lane halves of a wave: v_permlane32_swap_b32 swaps a's upper half with b's lower half (gfx950), one vector
+// instruction where __shfl_xor(v, 32) is a ds_bpermute_b32 round trip through the LDS crossbar.  (The instruction by hand: the builtin's
+// two results were folded into one by hipcc 7.0 when both inputs hold the same value.)  tools/ubench/permlane_check.hip checks both.
+__device__ __forceinline__ void swap_halves(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float xor32_max(float v) { float a = v, b = v; swap_halves(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor32_sum(float v) { float a = v, b = v; swap_halves(a, b); return a + b; }
+
 // ---------------------------------------------------------------- math
 // GELU(x) = x Phi(x), Phi(x) = 0.5 (1 + erf(x / sqrt 2)).  erfc(|z|) = poly(t) exp(-z^2), t = 1 / (1 + p |z|)
 // (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute): one exp and one reciprocal serve Phi AND the density term of the

@@ -101,13 +101,13 @@ __global__ __launch_bounds__(128) void lawin_attn_fwd_mfma_kernel(LawinAttnArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.c2;      // c2 > 0: scale and log2 e go into the exponent's fma
+        mx = xor32_max(mx) * a.c2;      // c2 > 0: scale and log2 e go into the exponent's fma
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], a.c2, -mx)); s[kt][r] = p; l += p; }
-        l += __shfl_xor(l, 32, 64);
+        l = xor32_sum(l);
         floatx16 oacc[TD];
 #pragma unroll
         for (int t = 0; t < TD; ++t)
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(128) void lawin_attn_bwd_mfma_kernel(LawinAttnArgs 
             kf[t][ks] = *(const bf16x8*)(pgw + (int64_t)(t * 32 + j) * 2 * a.inter + ks * 16 + 8 * h);
             vf[t][ks] = *(const bf16x8*)(pgw + (int64_t)(t * 32 + j) * 2 * a.inter + a.inter + ks * 16 + 8 * h);
         }
-        dl[t] = dot + __shfl_xor(dot, 32, 64);
+        dl[t] = xor32_sum(dot);
         ls[t] = a.lse[(wi * a.heads + hd) * 64 + t * 32 + j];
         if (h == 0) { lsd[t * 32 + j] = ls[t]; lsd[64 + t * 32 + j] = dl[t]; }
     }
@@ -323,13 +323,13 @@ __global__ __launch_bounds__(128) void lawin_attn_fwd_grp_kernel(LawinAttnArgs a
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.c2;
+            mx = xor32_max(mx) * a.c2;
             float l = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], a.c2, -mx)); s[kt][r] = p; l += p; }
-            l += __shfl_xor(l, 32, 64);
+            l = xor32_sum(l);
             linv[hh] = 1.f / l;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(128) void lawin_attn_bwd_grp_kernel(LawinAttnArgs a
             float dot = 0.f;                             // this lane half's share of head hh (zero when the head lives in the other half)
 #pragma unroll
             for (int e = 0; e < 8; ++e) dot += ((8 * h + e) / DH == hh) ? (float)dof[t][e] * (float)of[e] : 0.f;
-            dl[t][hh] = (dot + __shfl_xor(dot, 32, 64)) * a.scale;
+            dl[t][hh] = xor32_sum(dot) * a.scale;
             ls[t][hh] = a.lse[(wi * a.heads + gp * G + hh) * 64 + t * 32 + j];
             if (h == 0) { lsd[hh * 128 + t * 32 + j] = ls[t][hh]; lsd[hh * 128 + 64 + t * 32 + j] = dl[t][hh]; }
         }
