@@ -478,7 +478,7 @@ int ss_inject_fuse_sum(int dtype, const void* local, int64_t ldl, const void* ga
 /* ---- TopFormer training step (train.py:45-52 trains TopFormerModel('B', head refiner); modules/topformer.py in train mode):
  * the backward-side kernels the inference path has no use for.
  * ss_dwconvk_dgrad: data gradient of ss_dwconvk_fwd for stride 1 / 2 and the asymmetric AutoPadding (modules/layers.py:146-164;
- *   InvertedResidual conv_dw, modules/topformer.py:166-184): g [B*Ho*Wo][C] -> dx [B*H*W][C]; wkkc as the forward's.  C % 8 == 0.
+ *   InvertedResidual conv_dw, modules/topformer.py:166-184): g [B*Ho*Wo][C] -> dx [B*H*W][C]; wkkc as the forward's.  C % 8 == 0, k in {1, 3, 5, 7}.
  * ss_dwconvk_wgrad_s: the weight / bias gradient for the same geometry, dw_db = [(k*k + 1)][C] fp32 (taps tap-major, then the bias
  *   gradient); k in {3, 5}, C % 8 == 0; workspace >= 512 * (k*k+1) * C floats.
  * ss_avgpool_bwd: gradient of ss_avgpool (PyramidPoolAgg, modules/topformer.py:527-552); g may be a channel slice (row pitch ldg).

@@ -23,9 +23,12 @@ inline int tt_blocks(int64_t items, int cap = 8192) { int64_t b = cdiv(items, 25
 
 // ------------------------------------------------------------------ depthwise k x k, stride s: data gradient
 // dx[b, y, x, c] = sum_{ky, kx} w[ky, kx, c] * g[b, (y + pt - ky) / s, (x + pl - kx) / s, c]   over taps whose quotient is exact and in range
-template <typename T>
+// Compile-time K and S: the taps that can contribute to an input pixel are ky = ky0, ky0 + S, ... with ky0 = (y + pt) % S, i.e. ceil(K / S)
+// per axis; every one is an unconditional load from a clamped position, masked where the tap or its output pixel does not exist.
+template <typename T, int K, int S>
 __global__ __launch_bounds__(256) void dwk_dgrad_kernel(const T* __restrict__ g, const float* __restrict__ w, T* __restrict__ dx, int B, int H, int W,
-                                                        int C, int k, int s, int pt, int pl, int Ho, int Wo) {
+                                                        int C, int pt, int pl, int Ho, int Wo) {
+    constexpr int NT = (K + S - 1) / S;
     const int nch = C / 8;
     const int64_t items = (int64_t)B * H * W * nch;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
@@ -34,23 +37,30 @@ __global__ __launch_bounds__(256) void dwk_dgrad_kernel(const T* __restrict__ g,
         const int x = (int)(p % W); p /= W;
         const int y = (int)(p % H);
         const int b = (int)(p / H);
-        F8 acc = zero8();
-        for (int ky = 0; ky < k; ++ky) {
-            const int ny = y + pt - ky;
-            if (ny < 0 || ny % s) continue;
-            const int oy = ny / s;
-            if (oy >= Ho) continue;
-            for (int kx = 0; kx < k; ++kx) {
-                const int nx = x + pl - kx;
-                if (nx < 0 || nx % s) continue;
-                const int ox = nx / s;
-                if (ox >= Wo) continue;
-                const F8 gv = load8(g + (((int64_t)b * Ho + oy) * Wo + ox) * C + ch * 8);
-                const F8 wv = load8(w + (int64_t)(ky * k + kx) * C + ch * 8);
+        const int ky0 = (y + pt) % S, kx0 = (x + pl) % S;
+        const T* gb = g + (int64_t)b * Ho * Wo * C + ch * 8;
+        const float* wb = w + ch * 8;
+        F8 gv[NT][NT], wv[NT][NT]; float m[NT][NT];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc.v[e] = fmaf(gv.v[e], wv.v[e], acc.v[e]);
+        for (int a = 0; a < NT; ++a) {
+            const int ky = ky0 + a * S, oy = (y + pt - ky) / S;                   // exact: y + pt - ky is a multiple of S (or negative)
+            const bool yok = ky < K && y + pt - ky >= 0 && oy < Ho;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const int kx = kx0 + c * S, ox = (x + pl - kx) / S;
+                const bool ok = yok && kx < K && x + pl - kx >= 0 && ox < Wo;
+                m[a][c] = ok ? 1.f : 0.f;
+                gv[a][c] = load8(gb + ((int64_t)(ok ? oy : 0) * Wo + (ok ? ox : 0)) * C);
+                wv[a][c] = load8(wb + (int64_t)(ok ? ky * K + kx : 0) * C);
             }
         }
+        F8 acc = zero8();
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc.v[e] = fmaf(gv[a][c].v[e] * m[a][c], wv[a][c].v[e], acc.v[e]);
         store8(dx + (((int64_t)b * H + y) * W + x) * C + ch * 8, acc);
     }
 }
@@ -59,7 +69,7 @@ __global__ __launch_bounds__(256) void dwk_dgrad_kernel(const T* __restrict__ g,
 // dw[ky, kx, c] = sum_{b, oy, ox} g[b, oy, ox, c] * x[b, oy*s - pt + ky, ox*s - pl + kx, c];  db[c] = sum g.
 // A thread owns CH consecutive channels of one pixel lane and all K*K + 1 sums for them (CH = 8 for 3x3, 4 for 5x5: 80 / 104
 // accumulators); consecutive threads take consecutive channel chunks of one pixel, so a wave reads whole pixel rows; the pixel lanes of
-// a workgroup are combined through LDS in a fixed order; partial [nb][(K*K+1)][C], reduced by dwk_wgrad_final.
+// a workgroup are combined through LDS in a fixed order; partial [nb][(K*K+1)][C], reduced by colreduce_final_kernel.
 template <typename T, int CH> __device__ __forceinline__ void load_n(const T* p, float (&v)[CH]);
 template <> __device__ __forceinline__ void load_n<float, 8>(const float* p, float (&v)[8]) { const F8 r = load8(p);
 #pragma unroll
@@ -97,18 +107,22 @@ __global__ __launch_bounds__(256) void dwk_wgrad_kernel(const T* __restrict__ g,
             load_n<T, CH>(g + p * C + c, gv);
 #pragma unroll
             for (int e = 0; e < CH; ++e) acc[KK][e] += gv[e];
+            // every tap is an unconditional load from a clamped position (a load under a branch is waited for at the join: K * K round
+            // trips per pixel); taps outside the image take the gradient times zero
+            const T* xb = x + (int64_t)b * H * W * C + c;
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
                 const int iy = oy * s - pt + ky;
-                if (iy < 0 || iy >= H) continue;
+                const bool yok = iy >= 0 && iy < H;
+                const int64_t rowoff = (int64_t)min(max(iy, 0), H - 1) * W;
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
                     const int ix = ox * s - pl + kx;
-                    if (ix < 0 || ix >= W) continue;
+                    const float m = (yok && ix >= 0 && ix < W) ? 1.f : 0.f;
                     float xv[CH];
-                    load_n<T, CH>(x + (((int64_t)b * H + iy) * W + ix) * C + c, xv);
+                    load_n<T, CH>(xb + (rowoff + min(max(ix, 0), W - 1)) * C, xv);
 #pragma unroll
-                    for (int e = 0; e < CH; ++e) acc[ky * K + kx][e] = fmaf(gv[e], xv[e], acc[ky * K + kx][e]);
+                    for (int e = 0; e < CH; ++e) acc[ky * K + kx][e] = fmaf(gv[e] * m, xv[e], acc[ky * K + kx][e]);
                 }
             }
         }
@@ -129,13 +143,6 @@ __global__ __launch_bounds__(256) void dwk_wgrad_kernel(const T* __restrict__ g,
             }
         }
     }
-}
-__global__ void dwk_wgrad_final(const float* __restrict__ partial, int nb, int n, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[(int64_t)b * n + i];
-    out[i] = s;
 }
 
 // ------------------------------------------------------------------ exact-window average pooling: gradient
@@ -466,12 +473,20 @@ __global__ __launch_bounds__(256) void inject_bwd_final_kernel(const float* __re
 // g [B*Ho*Wo, C] -> dx [B*H*W, C]; wkkc: tap-major [k*k, C] fp32 (NOT flipped: the kernel walks the taps of the forward)
 extern "C" int ss_dwconvk_dgrad(int dtype, const void* g, const float* wkkc, void* dx, int B, int H, int W, int C, int k, int stride,
                                 int pad_top, int pad_left, int Ho, int Wo, hipStream_t stream) {
-    SS_CHECK(g && wkkc && dx && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0 && k >= 1 && k <= 7 && (stride == 1 || stride == 2) &&
-             pad_top >= 0 && pad_left >= 0, "ss_dwconvk_dgrad: bad arguments (C=%d k=%d stride=%d)", C, k, stride);
+    SS_CHECK(g && wkkc && dx && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0 && k >= 1 && k <= 7 && (k & 1) && (stride == 1 || stride == 2) &&
+             pad_top >= 0 && pad_left >= 0, "ss_dwconvk_dgrad: bad arguments (C=%d k=%d stride=%d; k must be 1, 3, 5 or 7)", C, k, stride);
     SS_CHECK(aligned16(g) && aligned16(dx) && aligned16(wkkc), "ss_dwconvk_dgrad: pointers must be 16-byte aligned");
     const int64_t items = (int64_t)B * H * W * (C / 8);
-    SS_DISPATCH(dtype, hipLaunchKernelGGL((dwk_dgrad_kernel<T>), dim3(tt_blocks(items, 16384)), dim3(256), 0, stream, (const T*)g, wkkc, (T*)dx, B, H, W, C,
-                                          k, stride, pad_top, pad_left, Ho, Wo));
+#define SS_DWK_DGRAD(K, S) SS_DISPATCH(dtype, hipLaunchKernelGGL((dwk_dgrad_kernel<T, K, S>), dim3(tt_blocks(items, 16384)), dim3(256), 0, stream, (const T*)g, wkkc, \
+                                                        (T*)dx, B, H, W, C, pad_top, pad_left, Ho, Wo))
+    switch (k * 10 + stride) {
+        case 11: SS_DWK_DGRAD(1, 1); break; case 12: SS_DWK_DGRAD(1, 2); break;
+        case 31: SS_DWK_DGRAD(3, 1); break; case 32: SS_DWK_DGRAD(3, 2); break;
+        case 51: SS_DWK_DGRAD(5, 1); break; case 52: SS_DWK_DGRAD(5, 2); break;
+        case 71: SS_DWK_DGRAD(7, 1); break; case 72: SS_DWK_DGRAD(7, 2); break;
+        default: return ss_fail(-1, "ss_dwconvk_dgrad: k must be 1, 3, 5 or 7 (k=%d)", k);
+    }
+#undef SS_DWK_DGRAD
     SS_LAUNCH_CHECK();
     return 0;
 }
@@ -497,7 +512,7 @@ extern "C" int ss_dwconvk_wgrad_s(int dtype, const void* g, const void* x, float
     else SS_DISPATCH(dtype, hipLaunchKernelGGL((dwk_wgrad_kernel<T, 5, 4>), grid, dim3(256), 0, stream, (const T*)g, (const T*)x, workspace, B, H, W, C,
                                                stride, pad_top, pad_left, Ho, Wo, cpb));
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dwk_wgrad_final, dim3((unsigned)cdiv(rows * C, 256)), dim3(256), 0, stream, (const float*)workspace, nb, rows * C, dw_db);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(rows * C, 8), 1), dim3(256), 0, stream, (const float*)workspace, nb, rows * C, 1.f, dw_db, 0);
     SS_LAUNCH_CHECK();
     return 0;
 }
