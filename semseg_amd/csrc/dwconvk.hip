@@ -50,53 +50,6 @@ __global__ __launch_bounds__(256) void dwconvk_fwd_kernel(const T* __restrict__ 
     }
 }
 
-// The same with compile-time K and stride and every tap an unconditional load from a clamped position (zero weight where the tap lies
-// outside the image): the taps of a pixel travel together instead of one round trip per branch.  TopFormer's stride-2 3 x 3 / 5 x 5.
-template <typename T, int K, int S>
-__global__ __launch_bounds__(256) void dwconvk_fwd_ks_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-        T* __restrict__ y, int B, int H, int W, int C, int pt, int pl, int Ho, int Wo, int act, const T* __restrict__ res) {
-    const int chunks = C / 8;
-    const int64_t total = (int64_t)B * Ho * Wo * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % chunks) * 8; int64_t p = i / chunks;
-        const int ox = (int)(p % Wo); int64_t q = p / Wo; const int oy = (int)(q % Ho); const int64_t b = q / Ho;
-        float u[8];
-        if (bias) { F8 t = load8(bias + c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) u[e] = t.v[e]; }
-        else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) u[e] = 0.f; }
-        const int y0 = oy * S - pt, x0 = ox * S - pl;
-        const T* xb = x + b * H * W * C + c;
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const int sy = y0 + ky;
-            const bool yok = sy >= 0 && sy < H;
-            const int64_t rowoff = (int64_t)min(max(sy, 0), H - 1) * W;
-            F8 v[K], ww[K]; float m[K];
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const int sx = x0 + kx;
-                m[kx] = (yok && sx >= 0 && sx < W) ? 1.f : 0.f;
-                v[kx] = load8(xb + (rowoff + min(max(sx, 0), W - 1)) * C);
-                ww[kx] = load8(w + (ky * K + kx) * C + c);
-            }
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) u[e] = fmaf(v[kx].v[e], ww[kx].v[e] * m[kx], u[e]);
-        }
-        F8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o.v[e] = apply_act(u[e], act);
-        if (res) { const F8 r = load8(res + p * C + c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o.v[e] += r.v[e]; }
-        store8(y + p * C + c, o);
-    }
-}
-
 // ---- stride-1 tiled forward (k = 3, 5, 7; C % 32 == 0): the kernel above fetches k*k taps per output through L1 (12.9 ms per DNet
 // step for ConvNeXt's 7x7).  Here a workgroup stages a (8 + k - 1) x (64 + k - 1) pixel patch of 32 channels in LDS as four planes of
 // 8-channel vectors (lanes = consecutive x read consecutive 16-byte slots: conflict-free), wave q owns plane q (so the tap weights are
@@ -676,14 +629,6 @@ static int dwconvk_fwd_impl(int dtype, const void* x, const float* wkkc, const f
             if (k == 3) dwconvk_tile_launch<T, 3>((const T*)x, wkkc, bias, (T*)y, B, H, W, C, pad_top, pad_left, Ho, Wo, act, (const T*)res, stream);
             else if (k == 5) dwconvk_tile_launch<T, 5>((const T*)x, wkkc, bias, (T*)y, B, H, W, C, pad_top, pad_left, Ho, Wo, act, (const T*)res, stream);
             else dwconvk_tile_launch<T, 7>((const T*)x, wkkc, bias, (T*)y, B, H, W, C, pad_top, pad_left, Ho, Wo, act, (const T*)res, stream);
-        });
-        SS_LAUNCH_CHECK();
-        return 0;
-    }
-    if (stride == 2 && (k == 3 || k == 5)) {
-        SS_DISPATCH(dtype, {
-            if (k == 3) hipLaunchKernelGGL((dwconvk_fwd_ks_kernel<T, 3, 2>), dim3(blocks), dim3(256), 0, stream, (const T*)x, wkkc, bias, (T*)y, B, H, W, C, pad_top, pad_left, Ho, Wo, act, (const T*)res);
-            else hipLaunchKernelGGL((dwconvk_fwd_ks_kernel<T, 5, 2>), dim3(blocks), dim3(256), 0, stream, (const T*)x, wkkc, bias, (T*)y, B, H, W, C, pad_top, pad_left, Ho, Wo, act, (const T*)res);
         });
         SS_LAUNCH_CHECK();
         return 0;
