@@ -296,24 +296,28 @@ template <typename T> struct BnStatUpF {
 };
 
 // stats[0][c] = mean, stats[1][c] = rstd (biased variance); running stats updated like nn.BatchNorm2d (unbiased var)
-// 8 channels x 32 row-parts per block (double accumulation, fixed order)
+// CX channels x 256 / CX row-parts per block (double accumulation, fixed order).  CX = 8 normally; CX = 1 where few channels meet many
+// partial rows (the GEMM leaves one row per 128-row tile: 32768 rows for the 16-channel 512 x 512 layers of TopFormer, which two
+// workgroups of the CX = 8 form took 147 us to add up)
+template <int CX>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nb, int C, int64_t n, float eps, float momentum,
                                    float* __restrict__ stats, float* running_mean, float* running_var, int64_t* nbt,
                                    const void* __restrict__ x, int x_is_bf16) {
-    __shared__ double sh[2][32][9];
-    const int cx = threadIdx.x & 7, part = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cx;
+    constexpr int PARTS = 256 / CX;
+    __shared__ double sh[2][PARTS][CX + 1];
+    const int cx = threadIdx.x % CX, part = threadIdx.x / CX;
+    const int c = blockIdx.x * CX + cx;
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
     double s = 0.0, q = 0.0;
     if (c < C) {
 #pragma unroll 4
-        for (int b = part; b < nb; b += 32) { s += partial[((int64_t)b * 2 + 0) * C + c]; q += partial[((int64_t)b * 2 + 1) * C + c]; }
+        for (int b = part; b < nb; b += PARTS) { s += partial[((int64_t)b * 2 + 0) * C + c]; q += partial[((int64_t)b * 2 + 1) * C + c]; }
     }
     sh[0][part][cx] = s; sh[1][part][cx] = q;
     __syncthreads();
     if (part != 0 || c >= C) return;
     s = 0.0; q = 0.0;
-    for (int k = 0; k < 32; ++k) { s += sh[0][k][cx]; q += sh[1][k][cx]; }
+    for (int k = 0; k < PARTS; ++k) { s += sh[0][k][cx]; q += sh[1][k][cx]; }
     const double shift = !x ? 0.0 : x_is_bf16 ? (double)(float)((const bf16*)x)[c] : (double)((const float*)x)[c];
     double md = s / (double)n, var = q / (double)n - md * md, mu = shift + md;
     if (var < 0) var = 0;
@@ -326,6 +330,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
+// (channels, partial rows, stream, kernel arguments ...)
+#define SS_BN_FINALIZE(CH, NB, STREAM, ...) do { \
+        if (cdiv((CH), 8) < 32 && (NB) > 1024) hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((unsigned)(CH)), dim3(256), 0, STREAM, __VA_ARGS__); \
+        else hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3((unsigned)cdiv((CH), 8)), dim3(256), 0, STREAM, __VA_ARGS__); \
+    } while (0)
+
 extern "C" int ss_bn_stats(int dtype, const void* x, int64_t ld, int64_t rows, int C, float eps, float momentum, float* stats,
                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float* workspace,
                            int64_t ws_bytes, hipStream_t stream) {
@@ -337,7 +347,7 @@ extern "C" int ss_bn_stats(int dtype, const void* x, int64_t ld, int64_t rows, i
         hipLaunchKernelGGL((colreduce_partial_kernel<BnStatF<T>>), dim3(g.nb, 1), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
     });
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, g.nb, C, rows, eps, momentum,
+    SS_BN_FINALIZE(C, g.nb, stream, workspace, g.nb, C, rows, eps, momentum,
                        stats, running_mean, running_var, num_batches_tracked, x, dtype == SS_BF16 ? 1 : 0);
     SS_LAUNCH_CHECK();
     return 0;
@@ -397,7 +407,7 @@ extern "C" int ss_bn_stats_up(int dtype, const void* x, int64_t ldx, const float
         hipLaunchKernelGGL((colreduce_partial_kernel<BnStatUpF<T>>), dim3(g.nb, 1), dim3(256), 0, stream, f, rows, C, g.cpb, g.rpb, workspace);
     });
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, stream, workspace, nb, C, rows, eps, momentum,
+    SS_BN_FINALIZE(C, nb, stream, workspace, nb, C, rows, eps, momentum,
                        stats, running_mean, running_var, num_batches_tracked, x, dtype == SS_BF16 ? 1 : 0);
     SS_LAUNCH_CHECK();
     return 0;
@@ -427,7 +437,7 @@ extern "C" int ss_gemm_nt_bn_stats(int dtype, const void* A, int64_t lda, const 
             SS_CHECK(ws_bytes >= nb * 2 * N * 4, "ss_gemm_nt_bn_stats: workspace too small");
             int rc = ss_fast_nt_launch(f, stream);
             if (rc) return rc;
-            hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(N, 8)), dim3(256), 0, stream, workspace, (int)nb, (int)N, M, eps, momentum,
+            SS_BN_FINALIZE(N, (int)nb, stream, workspace, (int)nb, (int)N, M, eps, momentum,
                                stats, running_mean, running_var, num_batches_tracked, (const void*)nullptr, 0);
             SS_LAUNCH_CHECK();
             return 0;
