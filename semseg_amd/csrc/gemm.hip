@@ -306,6 +306,8 @@ extern "C" int ss_gemm_nt(int dtype, int out_f32, const void* A, int64_t lda, co
     SS_CHECK(!res || ldr >= N, "ss_gemm_nt: bad ldr");
     SS_CHECK(!rowscale || rows_per_scale > 0, "ss_gemm_nt: rows_per_scale must be > 0");
     SS_CHECK(cdiv(M, 128) * cdiv(N, 64) < 2147483647LL, "ss_gemm_nt: too many tiles");
+    if (!out_f32 && !res && !rowscale && act == 0 && ss_rows_nt_ok(dtype, A, lda, C, ldc, M, N, K))
+        return ss_rows_nt_launch(dtype, A, lda, B, ldb, C, ldc, M, N, K, bias, stream);
     if (dtype == SS_BF16 && !res && !rowscale && act == 0 && ss_tinym_nt_ok(M, N, K, A, lda, B, ldb))
         return ss_tinym_nt_launch((const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, out_f32, M, N, K, bias, stream);
     if (dtype == SS_BF16 && !out_f32) {
@@ -468,6 +470,9 @@ static int gemm_tn_impl(int dtype, const void* A, int64_t lda, const void* B, in
         f.k_per_split = rps; f.pm = *pm;
         if (colsum && ns <= kColsumWsRows) { f.colsum_ws = cs_ws; cs_fused = true; }
         int rc = ss_patch_tn_launch(f, ns, stream);
+        if (rc) return rc;
+    } else if (!rowkeep && ss_smallmn_tn_ok(dtype, A, lda, B, ldb, M, N)) {
+        int rc = ss_smallmn_tn_launch(dtype, A, lda, B, ldb, (float*)workspace, N, R, rps, ns, stream);
         if (rc) return rc;
     } else if (dtype == SS_BF16 && ss_skinny_tn_ok(B, ldb, M, N)) {
         FastGemm f{};

@@ -78,6 +78,12 @@ bool ss_fast_tn_ok(const void* A, int64_t lda, const void* B, int64_t ldb, int64
 int ss_fast_tn_launch(FastGemm p, int nsplit, hipStream_t st);
 int ss_patch_nt_launch(FastGemm p, hipStream_t st);
 int ss_patch_tn_launch(FastGemm p, int nsplit, hipStream_t st);
+bool ss_rows_nt_ok(int dtype, const void* A, int64_t lda, const void* C, int64_t ldc, int64_t M, int64_t N, int64_t K);
+int ss_rows_nt_launch(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                      const float* bias, hipStream_t st);
+bool ss_smallmn_tn_ok(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N);
+int ss_smallmn_tn_launch(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* slabs, int64_t N, int64_t R, int64_t rps, int nsplit,
+                         hipStream_t st);
 bool ss_skinny_nt_ok(const FastGemm& p);
 int ss_skinny_nt_launch(const FastGemm& p, hipStream_t st);
 bool ss_tinym_nt_ok(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb);      // M <= 16 rows: a wave per output column

@@ -101,6 +101,125 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_kernel(const bf16* __restr
     }
 }
 
+// ------------------------------------------------------------------ both sides narrow (K, N in {8, 16, 32}; the 8-channel maps of the
+// RefinerHead at 256 x 256, modules/heads.py:173-269): a THREAD owns a row.  The kernels above give a lane eight columns of the wide side
+// and walk rows one at a time, which with N = 8 leaves 63 of 64 lanes idle (1048576 x 8 x 8: 125 us for 34 MB).  Weights sit in LDS as
+// fp32 and are read as broadcasts.
+template <typename T, int K, int N>
+__global__ __launch_bounds__(256) void gemm_nt_rows_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
+                                                           T* __restrict__ C, int64_t ldc, int64_t M, const float* __restrict__ bias) {
+    __shared__ __attribute__((aligned(16))) float w[N][K];
+    __shared__ float bs[N];
+    for (int i = threadIdx.x; i < N * K; i += 256) w[i / K][i % K] = (float)B[(int64_t)(i / K) * ldb + i % K];
+    for (int i = threadIdx.x; i < N; i += 256) bs[i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < M; row += (int64_t)gridDim.x * 256) {
+        float a[K];
+#pragma unroll
+        for (int c = 0; c < K / 8; ++c) {
+            const F8 v = load8(A + row * lda + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[c * 8 + e] = v.v[e];
+        }
+#pragma unroll
+        for (int c = 0; c < N / 8; ++c) {
+            F8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float acc = bs[c * 8 + j];
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc = fmaf(a[k], w[c * 8 + j][k], acc);
+                o.v[j] = acc;
+            }
+            store8(C + row * ldc + c * 8, o);
+        }
+    }
+}
+
+// dtype: SS_BF16 or SS_F32 (operands and output alike)
+bool ss_rows_nt_ok(int dtype, const void* A, int64_t lda, const void* C, int64_t ldc, int64_t M, int64_t N, int64_t K) {
+    auto narrow = [](int64_t v) { return v == 8 || v == 16 || v == 32; };
+    const int al = dtype == SS_F32 ? 4 : 8;            // elements per 16 bytes
+    return (dtype == SS_BF16 || dtype == SS_F32) && narrow(K) && narrow(N) && M >= 4096 && lda % al == 0 && ldc % al == 0 && aligned16(A) && aligned16(C);
+}
+
+int ss_rows_nt_launch(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                      const float* bias, hipStream_t st) {
+    const int64_t need = cdiv(M, 256);
+    const dim3 grid((unsigned)(need < 8192 ? need : 8192)), block(256);
+#define SS_ROWS_NT(K, N) SS_DISPATCH(dtype, hipLaunchKernelGGL((gemm_nt_rows_kernel<T, K, N>), grid, block, 0, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, bias))
+    switch ((int)K * 100 + (int)N) {
+        case 808: SS_ROWS_NT(8, 8); break;    case 816: SS_ROWS_NT(8, 16); break;   case 832: SS_ROWS_NT(8, 32); break;
+        case 1608: SS_ROWS_NT(16, 8); break;  case 1616: SS_ROWS_NT(16, 16); break; case 1632: SS_ROWS_NT(16, 32); break;
+        case 3208: SS_ROWS_NT(32, 8); break;  case 3216: SS_ROWS_NT(32, 16); break; case 3232: SS_ROWS_NT(32, 32); break;
+        default: return ss_fail(-1, "ss_rows_nt_launch: K=%d N=%d outside {8, 16, 32}", (int)K, (int)N);
+    }
+#undef SS_ROWS_NT
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// slab[z][8, N] = sum_r A[r, 8]^T . B[r, N] for N = 8 * CPL <= 32: a lane owns one ROW's eight-column chunk of B (256 / CPL rows per
+// workgroup step) and that row's eight A values; the lanes of a workgroup that share a chunk are added up through LDS in a fixed order.
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void gemm_tn_smallmn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
+                                                              float* __restrict__ slabs, int64_t R, int64_t rps) {
+    constexpr int RPB = 256 / CPL, N = 8 * CPL;        // rows per workgroup step
+    __shared__ float red[256][65];
+    const int tid = threadIdx.x, chunk = tid % CPL, rsub = tid / CPL;
+    const int64_t rbeg = (int64_t)blockIdx.x * rps;
+    const int64_t rend = rbeg + rps < R ? rbeg + rps : R;
+    float acc[8][8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[m][j] = 0.f;
+    for (int64_t r0 = rbeg; r0 < rend; r0 += 2 * RPB) {           // two rows per lane in flight
+        F8 av[2], bv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t r = r0 + u * RPB + rsub;
+            const bool ok = r < rend;
+            av[u] = ok ? load8(A + r * lda) : zero8();
+            bv[u] = ok ? load8(B + r * ldb + chunk * 8) : zero8();
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[m][j] = fmaf(av[u].v[m], bv[u].v[j], acc[m][j]);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid][m * 8 + j] = acc[m][j];
+    __syncthreads();
+    float* slab = slabs + (int64_t)blockIdx.x * 8 * N;
+    for (int e = tid; e < CPL * 64; e += 256) {
+        const int ch = e / 64, mj = e % 64, m = mj >> 3, j = mj & 7;
+        float sum = 0.f;
+        for (int t = 0; t < RPB; ++t) sum += red[t * CPL + ch][mj];
+        slab[(int64_t)m * N + ch * 8 + j] = sum;
+    }
+}
+
+// both sides narrow (M = 8, N in {8, 16, 32}), bf16 or fp32 operands
+bool ss_smallmn_tn_ok(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N) {
+    const int al = dtype == SS_F32 ? 4 : 8;
+    return (dtype == SS_BF16 || dtype == SS_F32) && M == 8 && (N == 8 || N == 16 || N == 32) && lda % al == 0 && ldb % al == 0 && aligned16(A) && aligned16(B);
+}
+
+int ss_smallmn_tn_launch(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* slabs, int64_t N, int64_t R, int64_t rps, int nsplit,
+                         hipStream_t st) {
+    const dim3 grid((unsigned)nsplit), block(256);
+#define SS_SMN(CPL) SS_DISPATCH(dtype, hipLaunchKernelGGL((gemm_tn_smallmn_kernel<T, CPL>), grid, block, 0, st, (const T*)A, lda, (const T*)B, ldb, slabs, R, rps))
+    if (N == 8) SS_SMN(1); else if (N == 16) SS_SMN(2); else SS_SMN(4);
+#undef SS_SMN
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
 bool ss_skinny_nt_ok(const FastGemm& p) {
     return p.K <= 8 && p.N % 8 == 0 && p.ldc % 8 == 0 && aligned16(p.C) && !p.res && !p.rowscale && p.act == 0;
 }

@@ -89,6 +89,39 @@ def test_gemm_nt_bf16_fast_path(ops, M, N, K):
     assert rel(out3, big[:, 8:8 + K].float().cpu() @ q(b, dtype).t()) < 1e-2
 
 
+@pytest.mark.parametrize('M,N,K', [(70001, 8, 8), (5000, 8, 32), (65536, 32, 8), (4100, 16, 16), (9000, 32, 32), (4096, 16, 8)])
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_gemm_nt_both_sides_narrow(ops, dtype, M, N, K):
+    """K, N in {8, 16, 32} (the 8-channel maps of the RefinerHead, fp32 there): the thread-per-row kernel, dense and into / out of channel slices."""
+    a, b, bias = rnd(M, K), rnd(N, K, seed=1) / math.sqrt(K), rnd(N, seed=2)
+    ref = q(a, dtype) @ q(b, dtype).t() + bias
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel(ops.gemm_nt(dev(a, dtype), dev(b, dtype), bias=dev(bias)), ref) < tol
+    assert rel(ops.gemm_nt(dev(a, dtype), dev(b, dtype)), ref - bias) < tol
+    wide = torch.full((M, N + 16), 7.0, dtype=dtype, device='cuda')
+    big = dev(rnd(M, K + 24, seed=4), dtype)
+    ops.gemm_nt(big[:, 8:8 + K], dev(b, dtype), bias=dev(bias), out=wide[:, 8:8 + N])
+    assert rel(wide[:, 8:8 + N], big[:, 8:8 + K].float().cpu() @ q(b, dtype).t() + bias) < tol
+    assert float((wide[:, :8] - 7).abs().max()) == 0 and float((wide[:, 8 + N:] - 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize('R,N', [(5000, 8), (70001, 32), (4097, 16), (300000, 8)])
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_gemm_tn_both_sides_narrow(ops, dtype, R, N):
+    """[R, 8]^T . [R, N], N <= 32: a lane per row instead of a wave per row; strided operands; bit-reproducible."""
+    a, b = rnd(R, 8), rnd(R, N, seed=1)
+    ref = q(a, dtype).t() @ q(b, dtype)
+    tol = 2e-3 if dtype == torch.bfloat16 else 1e-4
+    out = ops.gemm_tn(dev(a, dtype), dev(b, dtype))
+    assert rel(out, ref) < tol
+    assert torch.equal(out, ops.gemm_tn(dev(a, dtype), dev(b, dtype)))
+    big_a, big_b = dev(rnd(R, 24, seed=3), dtype), dev(rnd(R, N + 8, seed=5), dtype)
+    out2 = ops.gemm_tn(big_a[:, 8:16], big_b[:, :N])
+    assert rel(out2, big_a[:, 8:16].float().cpu().t() @ big_b[:, :N].float().cpu()) < tol
+    out3, cs = ops.gemm_tn(dev(a, dtype), dev(b, dtype), colsum=True)
+    assert torch.equal(out3, out) and rel(cs, q(a, dtype).sum(0)) < tol
+
+
 @pytest.mark.parametrize('R,M,N', [(5000, 64, 64), (4097, 320, 1280), (9000, 512, 48 + 512), (1024, 128, 2048), (70, 8, 16), (3000, 1152, 320),
                                    (70001, 6, 512), (333, 3, 1032),
                                    (8192, 512, 256), (4096, 384, 512), (12288, 256, 328), (16384, 520, 768),     # 256-tile kernel, ragged tiles
