@@ -431,7 +431,10 @@ extern "C" int ss_gemm_nt_bn_stats(int dtype, const void* A, int64_t lda, const 
         FastGemm f{};
         f.A = (const bf16*)A; f.B = (const bf16*)B; f.C = C; f.M = M; f.N = (int)N; f.K = K; f.lda = lda; f.ldb = ldb; f.ldc = ldc;
         f.rows_per_scale = 1; f.k_per_split = K; f.res = (const bf16*)res; f.ldr = ldr;
-        if (!ss_skinny_nt_ok(f) && ss_fast_nt_ok(A, lda, B, ldb, C, ldc, M, N, K, res, ldr, nullptr)) {
+        // both sides narrow (K, N <= 32: TopFormer's 16-channel layers at 512 x 512): the thread-per-row product and a statistics pass over
+        // its 2 N bytes per row take 130 us where 32768 tiles of the fused kernel take 280
+        const bool narrow = !res && ss_rows_nt_ok(dtype, A, lda, C, ldc, M, N, K);
+        if (!narrow && !ss_skinny_nt_ok(f) && ss_fast_nt_ok(A, lda, B, ldb, C, ldc, M, N, K, res, ldr, nullptr)) {
             f.stat_ws = workspace;
             const int64_t nb = ss_fast_nt_stat_tiles(f);
             SS_CHECK(ws_bytes >= nb * 2 * N * 4, "ss_gemm_nt_bn_stats: workspace too small");

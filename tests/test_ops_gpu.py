@@ -89,7 +89,7 @@ def test_gemm_nt_bf16_fast_path(ops, M, N, K):
     assert rel(out3, big[:, 8:8 + K].float().cpu() @ q(b, dtype).t()) < 1e-2
 
 
-@pytest.mark.parametrize('M,N,K', [(70001, 8, 8), (5000, 8, 32), (65536, 32, 8), (4100, 16, 16), (9000, 32, 32), (4096, 16, 8)])
+@pytest.mark.parametrize('M,N,K', [(70001, 8, 8), (5000, 8, 32), (65536, 32, 8), (4100, 16, 16), (9000, 32, 32), (4096, 16, 8), (6000, 8, 16), (5000, 16, 32)])
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_gemm_nt_both_sides_narrow(ops, dtype, M, N, K):
     """K, N in {8, 16, 32} (the 8-channel maps of the RefinerHead, fp32 there): the thread-per-row kernel, dense and into / out of channel slices."""
