@@ -179,6 +179,15 @@ int ss_dwconv3_bwd(int dtype, const void* dy, const void* x, const float* w9c, c
 int ss_dwconv3_bwd_fused(int dtype, const void* dy, const void* x, const float* w9c, const float* bias, void* dx, float* dw_db,
                          int B, int H, int W, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
+/* The same pass fed by the gradient of fc2's OUTPUT (modules/segformer.py:58-63 backward: Mix-FFN's fc2 follows the depthwise stage):
+ * da2 = (dout . W2) * keep[image] is formed row by row on the matrix cores inside the kernel, the [B*H*W, C] tensor da2 is neither
+ * written nor read.  dout [B*H*W, K] bf16 (gradient of the block output on this branch), w2t [C, K] bf16 (fc2.weight transposed: one row
+ * per hidden channel), keep [B] fp32 DropPath multipliers or NULL, x = fc1's output [B*H*W, C]; GELU between the two.  bf16, C % 64 == 0,
+ * K in {64, 128} (ss_dwconv3_bwd_fc2_ok says where it runs; SS_DW_FC2=0 switches it off).  workspace as above. */
+int ss_dwconv3_bwd_fc2_ok(int dtype, int B, int H, int W, int C, int K);
+int ss_dwconv3_bwd_fc2(int dtype, const void* dout, const void* w2t, const float* keep, const void* x, const float* w9c, const float* bias,
+                       void* dx, float* dw_db, int B, int H, int W, int C, int K, float* workspace, int64_t ws_bytes, hipStream_t stream);
+
 /* ---- general depthwise k x k convolution on channels-last maps: ConvNeXt 7x7 s1 p3 (modules/convnext.py:27,39) and the TopFormer
  * token-pyramid 3x3 / 5x5, stride 1 / 2 with the asymmetric AutoPadding of modules/layers.py:146-164 (modules/topformer.py:166-184).
  * wkkc: tap-major [k*k][C] fp32.  act: 0 none, 1 GELU(erf), 2 ReLU, 3 ReLU6.  The data gradient (stride 1) is this entry point with

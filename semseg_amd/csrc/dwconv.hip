@@ -10,6 +10,7 @@
 //             dx = dw_flipped(g) reuses the forward kernel with the flipped taps and no bias / activation.
 #include "common.h"
 #include "colreduce.h"
+#include "gemm_fast.h"
 
 #define DW_UNROLL 9                                   // rows per loop iteration: divides the strip height, a multiple of the window height 3
 // forward kernel: rows in flight per thread (the ring) and its loop unroll, a multiple of both the ring depth and the window height
@@ -543,6 +544,256 @@ __global__ __launch_bounds__(256, OCC) void dwconv3_bwd_fused_kernel(const T* __
     }
 }
 
+// ------------------------------------------------------------------ fused backward, a lane per image column (bf16, C % 64 == 0)
+// The kernel above hands every row of g to the column neighbours through LDS behind a workgroup barrier and fetches the left / right
+// window entries with loads of their own.  Here the 16 lanes of a DPP row ARE 16 adjacent image columns (tid = chunk lane * 16 +
+// column lane; a wave = 16 columns x 4 chunks of 4 channels): the neighbours' x and g are row_shr:1 / row_shl:1 of a lane's own value,
+// the row loop has no barrier and no LDS traffic, and a row costs two loads (the centre, and the column beyond the tile edge for
+// lanes 0 and 15 -- the same address as the centre for the lanes between, a cache hit) instead of three.  A wave instruction touches
+// 32 bytes of 16 pixels; the four waves of the workgroup read the four quarters of the same 128-byte lines.  Arithmetic and its order
+// are those of the kernel above (same results bit for bit).
+//
+// KS > 0: `dy` is not the gradient of the depthwise output but dout [pixels, 32 KS], the gradient of the Linear that follows it
+// (Mix-FFN fc2, modules/segformer.py:58-63), and the kernel forms its row of da2 = (dout . W2) * keep itself: this thread layout is
+// the accumulator layout of v_mfma_f32_16x16x32_bf16 with A = 16 rows of W2^T (channels) and B = 16 pixels of dout -- lane (column
+// j, k group) receives channels 4 kg .. 4 kg + 3 of column j.  The [pixels, 4C] tensor da2 (537 MB per block at MiT stage 1) is never
+// written or read; dout is re-read by the C / 64 channel groups out of L2.
+__device__ __forceinline__ float lane_left(float v, float edge) {    // value of lane - 1 within the row of 16; lane 0 receives `edge`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_right(float v, float edge) {   // value of lane + 1; lane 15 receives `edge`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
+}
+template <int NE>
+__device__ __forceinline__ void dwl_cvt_row(const vecn<bf16, NE> (&raw)[2], unsigned keepC, unsigned keepO, float (&row)[3][NE]) {
+    union { vecn<bf16, NE> v; unsigned u[NE / 2]; } c, o;
+    c.v = raw[0]; o.v = raw[1];
+#pragma unroll
+    for (int i = 0; i < NE / 2; ++i) { c.u[i] &= keepC; o.u[i] &= keepO; }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const float cv = (float)c.v[e], ov = (float)o.v[e];
+        row[1][e] = cv; row[0][e] = lane_left(cv, ov); row[2][e] = lane_right(cv, ov);
+    }
+}
+
+// KS > 0: everything the row loop reads from memory arrives by LDS-DMA in wave-private queues of three slots, issued by hand
+// (gemm_fast.h) -- the register file has no room for operands in flight (the kernel sits at 252 VGPRs without them), and with the
+// builtin hipcc treats a pending LDS-DMA as a flat access and turns every wait of the loop into vmcnt(0).
+//   x row:    one instruction per wave and row; lane l < 32 fetches 16 bytes (8 channels) of pixel l >> 1, lanes 32 .. 35 the two
+//             columns beyond the tile edges; a lane reads back its own 8 bytes and the edge column with ds_read_b64.
+//   dout row: KS instructions; instruction s leaves lane l's B fragment (pixel l & 15, k = 32 s + 8 (l >> 4) ..) at [s][l], where the
+//             same lane reads it back.
+// A step issues [x, dout x KS] in this order and nothing else but the dx store, so the waits are exact counts of what was issued since
+// (a store in between makes a wait stricter, never laxer).  `dep` is a register the fill must not overtake: a value read from the slot
+// being refilled, which makes the compiler wait for that LDS read before the fill is issued.
+__device__ __forceinline__ void dwl_dma(const void* g, unsigned lds_uniform, unsigned dep) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(lds_uniform), "v"(dep) : "memory");
+}
+template <int N> __device__ __forceinline__ void dwl_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int ACT, int KS, int DEPTH>
+__global__ __launch_bounds__(256, 2) void dwconv3_bwd_lane_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ w,
+        const float* __restrict__ bias, bf16* __restrict__ dxo, float* __restrict__ partial, int B, int H, int W, int C, DwFGeom g,
+        const bf16* __restrict__ w2t, const float* __restrict__ keep) {
+    constexpr int NE = 4, K = 32 * KS;
+    typedef vecn<bf16, NE> V;
+    constexpr bool LUT = DWF_LUT && ACT == 1;
+    __shared__ float2 lut[LUT ? GELU_LUT_N : 1];
+    const int tid = threadIdx.x, xs = tid & 15, cl = tid >> 4, kg = cl & 3;
+    if (LUT) { gelu_grad_lut_fill(lut, tid, 256); __syncthreads(); }
+    const int c = (blockIdx.y * 16 + cl) * NE;                  // C % 64 == 0: every chunk lane has its channels
+    float wt[9][NE], bv[NE], acc[10][NE];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) acc[k][e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) loadf<NE>(w + k * C + c, wt[k]);
+    loadf<NE>(bias + c, bv);
+    // A fragments (row = channel blockIdx.y * 64 + 16 wave + xs, k = 32 s + 8 kg ..) wait in LDS in fragment order: a ds_read_b128 per
+    // step and fragment instead of 4 KS registers held for the whole kernel
+    __shared__ bf16x8 wfs[KS > 0 ? KS : 1][256];
+    if (KS > 0) {
+        const bf16* wr = w2t + (int64_t)(blockIdx.y * 64 + (cl & ~3) * NE + xs) * K + 8 * kg;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wfs[s][tid] = *(const bf16x8*)(wr + 32 * s);
+    }
+    __shared__ bf16x8 bst[KS > 0 ? 4 * 3 * KS : 1][64];       // [wave][ring slot][s][lane]
+    constexpr int XSLOT = 640;                                // bytes per x slot: 36 lanes x 16, rounded up
+    __shared__ __attribute__((aligned(16))) char xq[KS > 0 ? 4 * 3 * XSLOT : 16];       // [wave][ring slot][lane]
+    __shared__ float shf_own[KS > 0 ? 1 : 256 * NE];
+    float* shf = KS > 0 ? (float*)&bst[0][0] : shf_own;      // the final combine reuses the dout queue (drained first)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const unsigned bbase = lds_addr(&bst[wave * 3 * KS][0]), xbase = lds_addr(xq + (KS > 0 ? wave * 3 * XSLOT : 0));
+    const V* xqw = (const V*)(xq + (KS > 0 ? wave * 3 * XSLOT : 0));     // XSLOT / 8 V per slot: centre of lane (xs, kg) at xs * 4 + kg, edge columns from 64
+    const int xci = xs * 4 + kg, xoi = 64 + (xs == 15 ? 4 : 0) + kg;
+    const int tiles_per_img = g.xtiles * g.ystrips, ntiles = B * tiles_per_img;
+    const int64_t rs = (int64_t)W * C, rsd = (int64_t)W * (KS > 0 ? K : C);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / tiles_per_img, rem = tile % tiles_per_img;
+        const int xx = (rem % g.xtiles) * 14 - 1 + xs, y0 = (rem / g.xtiles) * g.ty;
+        const bool colok = xx >= 0 && xx < W;
+        const bool inner = colok && xs > 0 && xs < 15;                       // this lane's dx / dW are its own
+        const int xc = xx < 0 ? 0 : (xx < W ? xx : W - 1);
+        const bool ook = colok && (xs == 0 ? xx > 0 : xs == 15 ? xx + 1 < W : false);   // the column beyond the tile edge exists
+        const unsigned mC = colok ? ~0u : 0u, mO = ook ? ~0u : 0u;
+        const int offO = ook ? (xs == 0 ? -C : C) : 0;
+        const int yend = min(H, y0 + g.ty);
+        const int ylast = min(H - 1, yend + 1);                  // last row of x any g of the strip reads
+        const int dlast = min(H - 1, yend);                      // last row of dy
+        const int rb = max(y0 - 1, 0);                           // row the base pointers stand on
+        const int64_t pix = ((int64_t)img * H + rb) * W + xc, off = pix * C + c;
+        const bf16* px = x + off;
+        const bf16* pd = KS > 0 ? dy + pix * K + 8 * kg : dy + off;
+        bf16* po = dxo + off;
+        const float kscale = (KS > 0 && keep) ? keep[img] : 1.f;
+        const int r0 = y0 - 1;
+        // the fill lane's own address: 16 bytes of a centre pixel (lanes 0 .. 31) or of an edge column (32 .. 35)
+        const bf16* pq = x;
+        if (KS > 0) {
+            const int t0 = (rem % g.xtiles) * 14 - 1;
+            const int qc = lane < 32 ? t0 + (lane >> 1) : (lane < 34 ? t0 - 1 : t0 + 16);
+            pq = x + (((int64_t)img * H + rb) * W + min(max(qc, 0), W - 1)) * C + blockIdx.y * 64 + wave * 16 + (lane & 1) * 8;
+        }
+        float win[3][3][NE], gw[3][3][NE];
+        V ring[3][2], dring[KS > 0 ? 1 : 3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) gw[a][b][e] = 0.f;
+        {
+            V raw[2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {                         // rows r0-1, r0, r0+1
+                const int rr = r0 - 1 + j;
+                const unsigned k = (rr >= 0 && rr < H) ? ~0u : 0u;
+                const bf16* p = px + (int64_t)(min(max(rr, 0), ylast) - rb) * rs;
+                raw[0] = raw_load<bf16, NE>(p); raw[1] = raw_load<bf16, NE>(p + offO);
+                dwl_cvt_row<NE>(raw, mC & k, mO & k, win[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int64_t xo = (int64_t)(min(max(r0 + 2 + j, 0), ylast) - rb) * rs;
+                const bf16* q = pd + (int64_t)(min(max(r0 + j, 0), dlast) - rb) * rsd;
+                if (KS == 0) {
+                    ring[(2 + j) % 3][0] = raw_load<bf16, NE>(px + xo); ring[(2 + j) % 3][1] = raw_load<bf16, NE>(px + xo + offO);
+                    dring[j] = raw_load<bf16, NE>(q);
+                } else {
+                    if (lane < 36) dwl_dma(pq + xo, xbase + ((2 + j) % 3) * XSLOT, 0u);
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) dwl_dma(q + 32 * s, bbase + (j * KS + s) * 1024, 0u);
+                }
+            }
+        }
+        const int nsteps = yend - y0 + 3;                        // rows y0-1 .. yend of g, and one more step: dx trails g by two rows
+        if (KS == 0) DW_DRAIN_PROLOGUE();
+        constexpr int UNR = 3;
+        for (int s0 = 0; s0 < nsteps; s0 += UNR) {
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) {
+                const int r = r0 + s0 + i;                        // the row of g this step produces
+                float u[NE], go[NE];
+                union { V v; unsigned w[NE / 2]; } d;
+                if (KS > 0) {
+                    floatx4 a4 = {0.f, 0.f, 0.f, 0.f};
+                    dwl_wait<2 + 2 * KS>();                         // the dout row issued three steps ago: two steps of [x, dout x KS] since
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfs[s][tid], bst[(wave * 3 + i % 3) * KS + s][lane], a4, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) d.v[e] = (bf16)(a4[e] * kscale);       // da2 as the GEMM would have stored it
+                } else {
+                    d.v = dring[i % 3];
+                    dring[i % 3] = raw_load<bf16, NE>(pd + (int64_t)(min(max(r + 3, 0), dlast) - rb) * rsd);
+                }
+                dw_taps<NE>(win[i % 3], win[(i + 1) % 3], win[(i + 2) % 3], wt, bv, u);
+                const unsigned live = (r >= 0 && r <= dlast && r <= yend && colok) ? ~0u : 0u;     // g is zero outside the image
+#pragma unroll
+                for (int j = 0; j < NE / 2; ++j) d.w[j] &= live;
+                float dact[NE];
+                if (LUT) gelu_grad_lut<NE>(lut, u, dact);
+                else if (ACT == 1) {
+                    float cdf[NE], ez[NE];
+                    gelu_parts_v<NE>(u, cdf, ez);
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) dact[e] = fmaf(u[e] * 0.3989422804014327f, ez[e], cdf[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    go[e] = ACT == 1 ? (float)d.v[e] * dact[e] : (float)d.v[e];
+                    go[e] = (float)(bf16)go[e];                   // the rounded g, as a stored g would be read back
+                }
+                // dx of row r-2 from g rows r-1 (ky = 0), r-2 (ky = 1), r-3 (ky = 2), column x+1-kx
+                {
+                    float o[NE];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) o[e] = 0.f;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) {
+                            o[e] = fmaf(wt[kx][e], gw[(i + 2) % 3][2 - kx][e], o[e]);
+                            o[e] = fmaf(wt[3 + kx][e], gw[(i + 1) % 3][2 - kx][e], o[e]);
+                            o[e] = fmaf(wt[6 + kx][e], gw[i % 3][2 - kx][e], o[e]);
+                        }
+                    V ov;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) ov[e] = (bf16)o[e];
+                    if (inner && r - 2 >= y0 && r - 2 < yend) *(V*)(po + (int64_t)(r - 2 - rb) * rs) = ov;
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {                    // slot of row r-3 is free now: row r moves in, with its neighbours
+                    gw[i % 3][1][e] = go[e]; gw[i % 3][0][e] = lane_left(go[e], 0.f); gw[i % 3][2][e] = lane_right(go[e], 0.f);
+                }
+                // weight / bias gradient: own rows and own columns only (halo g belongs to the neighbouring workgroup)
+                const float own = (inner && r >= y0 && r < yend) ? 1.f : 0.f;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) { const float gm = go[e] * own; acc[9][e] += gm;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        acc[kx][e] = fmaf(gm, win[i % 3][kx][e], acc[kx][e]);
+                        acc[3 + kx][e] = fmaf(gm, win[(i + 1) % 3][kx][e], acc[3 + kx][e]);
+                        acc[6 + kx][e] = fmaf(gm, win[(i + 2) % 3][kx][e], acc[6 + kx][e]);
+                    } }
+                const unsigned k = r + 2 < H ? ~0u : 0u;          // r + 2 >= y0 + 1 > 0
+                const int64_t xo = (int64_t)(min(max(r + 5, 0), ylast) - rb) * rs;
+                if (KS == 0) {
+                    dwl_cvt_row<NE>(ring[(i + 2) % 3], mC & k, mO & k, win[i % 3]);
+                    ring[(i + 2) % 3][0] = raw_load<bf16, NE>(px + xo); ring[(i + 2) % 3][1] = raw_load<bf16, NE>(px + xo + offO);
+                } else {
+                    dwl_wait<2 + 3 * KS>();                         // the x row issued three steps ago, its dout rows and two whole steps since
+                    union { V v[2]; unsigned w[NE]; } xr;
+                    xr.v[0] = xqw[((i + 2) % 3) * (XSLOT / 8) + xci]; xr.v[1] = xqw[((i + 2) % 3) * (XSLOT / 8) + xoi];
+                    dwl_cvt_row<NE>(xr.v, mC & k, mO & k, win[i % 3]);
+                    if (lane < 36) dwl_dma(pq + xo, xbase + ((i + 2) % 3) * XSLOT, xr.w[0] | xr.w[2]);
+                    const bf16* q = pd + (int64_t)(min(max(r + 3, 0), dlast) - rb) * rsd;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) dwl_dma(q + 32 * s, bbase + ((i % 3) * KS + s) * 1024, d.w[0]);
+                }
+            }
+        }
+    }
+    // combine the column lanes of each chunk lane through LDS in a fixed order
+    if (KS > 0) dwl_wait<0>();                                // fills issued past the last strip still land in the queue the combine reuses
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NE; ++e) shf[tid * NE + e] = acc[k][e];
+        __syncthreads();
+        if (xs == 0) {
+            float* dst = partial + ((int64_t)blockIdx.x * 10 + k) * C + c;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { float sum = 0.f;
+                for (int j = 0; j < 16; ++j) sum += shf[(cl * 16 + j) * NE + e];
+                dst[e] = sum; }
+        }
+    }
+}
+
 extern "C" int ss_dwconv3_fwd(int dtype, const void* x, const float* w9c, const float* bias, void* y, int B, int H, int W, int C,
                               int act, hipStream_t stream) {
     SS_CHECK(x && w9c && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "ss_dwconv3_fwd: bad arguments (C=%d)", C);
@@ -583,6 +834,12 @@ extern "C" int ss_dwconv3_bwd(int dtype, const void* dy, const void* x, const fl
     return 0;
 }
 
+// the lane-per-column kernel serves the geometry 16 columns x 16 chunk lanes with whole channel groups (SS_DW_LANE=0: the LDS-exchange kernel)
+static inline bool dwl_ok(const DwFGeom& g, int C) {
+    const char* e = getenv("SS_DW_LANE");
+    return g.xl == 16 && g.cpb == 16 && C % 64 == 0 && !(e && e[0] == '0');
+}
+
 // dx and dw_db in one pass: dx = d/dx of sum(dy * act(dw(x) + b)), dw_db = [10][C] fp32.  workspace: 1024 * 10 * C floats.
 extern "C" int ss_dwconv3_bwd_fused(int dtype, const void* dy, const void* x, const float* w9c, const float* bias, void* dx, float* dw_db,
                                     int B, int H, int W, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream) {
@@ -596,12 +853,50 @@ extern "C" int ss_dwconv3_bwd_fused(int dtype, const void* dy, const void* x, co
     SS_CHECK(ws_bytes >= nbg * 10 * C * 4, "ss_dwconv3_bwd_fused: workspace too small");
     dim3 grid((unsigned)nbg, geo.groups);
     SS_CHECK(act == 0 || act == 1, "ss_dwconv3_bwd_fused: act must be 0 (none) or 1 (GELU)");
+    if (dtype == SS_BF16 && dwl_ok(geo, C)) {
+        if (act) hipLaunchKernelGGL((dwconv3_bwd_lane_kernel<1, 0, 3>), grid, dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, w9c, bias, (bf16*)dx, workspace, B, H, W, C, geo, (const bf16*)nullptr, (const float*)nullptr);
+        else hipLaunchKernelGGL((dwconv3_bwd_lane_kernel<0, 0, 3>), grid, dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, w9c, bias, (bf16*)dx, workspace, B, H, W, C, geo, (const bf16*)nullptr, (const float*)nullptr);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(10 * C, 8), 1), dim3(256), 0, stream, workspace, (int)nbg, 10 * C, 1.f, dw_db, 0);
+        SS_LAUNCH_CHECK();
+        return 0;
+    }
     // fp32 (the parity path) keeps twice the bytes per window entry: one workgroup per SIMD pair there, two for bf16
 #define SS_DW_BWDF(T, NE, ACT) hipLaunchKernelGGL((dwconv3_bwd_fused_kernel<T, NE, ACT, sizeof(T) == 2 ? 2 : 1, DWF_UNR>), grid, dim3(256), 0, stream, (const T*)dy, (const T*)x, w9c, bias, (T*)dx, workspace, B, H, W, C, geo)
     if (dtype == SS_BF16) { if (act) SS_DW_BWDF(bf16, DWF_NE, 1); else SS_DW_BWDF(bf16, DWF_NE, 0); }
     else if (dtype == SS_F32) { if (act) SS_DW_BWDF(float, 4, 1); else SS_DW_BWDF(float, 4, 0); }
     else return ss_fail(-1, "ss_dwconv3_bwd_fused: unsupported dtype %d", dtype);
 #undef SS_DW_BWDF
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(10 * C, 8), 1), dim3(256), 0, stream, workspace, (int)nbg, 10 * C, 1.f, dw_db, 0);
+    SS_LAUNCH_CHECK();
+    return 0;
+}
+
+// The backward of Mix-FFN's depthwise stage fed by the gradient of fc2's OUTPUT (modules/segformer.py:58-63): da2 = (dout . W2) * keep is
+// formed row by row on the matrix cores inside the lane kernel and never stored.  dout [B*H*W, K] bf16, w2t [C, K] bf16 (fc2's weight
+// transposed: row = hidden channel), keep [B] fp32 or NULL, x = fc1's output [B*H*W, C].  ss_dwconv3_bwd_fc2_ok: 1 where it runs.
+extern "C" int ss_dwconv3_bwd_fc2_ok(int dtype, int B, int H, int W, int C, int K) {
+    if (dtype != SS_BF16 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 64 || !(K == 64 || K == 128)) return 0;
+    const char* e = getenv("SS_DW_FC2");
+    if (e && e[0] == '0') return 0;
+    return dwl_ok(dwf_geom(B, H, W, C, 4), C) ? 1 : 0;
+}
+extern "C" int ss_dwconv3_bwd_fc2(int dtype, const void* dout, const void* w2t, const float* keep, const void* x, const float* w9c, const float* bias,
+                                  void* dx, float* dw_db, int B, int H, int W, int C, int K, float* workspace, int64_t ws_bytes, hipStream_t stream) {
+    SS_CHECK(dout && w2t && x && w9c && bias && dx && dw_db && workspace, "ss_dwconv3_bwd_fc2: null argument");
+    SS_CHECK(ss_dwconv3_bwd_fc2_ok(dtype, B, H, W, C, K), "ss_dwconv3_bwd_fc2: unsupported shape (bf16, C %% 64 == 0, K in {64, 128}; C=%d K=%d)", C, K);
+    SS_CHECK(aligned16(x) && aligned16(dout) && aligned16(w2t) && aligned16(dx) && aligned16(w9c) && aligned16(bias), "ss_dwconv3_bwd_fc2: pointers must be 16-byte aligned");
+    SS_CHECK(dx != x && dx != dout, "ss_dwconv3_bwd_fc2: dx must not alias an input");
+    DwFGeom geo = dwf_geom(B, H, W, C, 4);
+    const int64_t ntiles = (int64_t)B * geo.xtiles * geo.ystrips;
+    SS_CHECK(ntiles < 2147483647LL && geo.groups < 65536, "ss_dwconv3_bwd_fc2: grid too large");
+    int64_t nbg = 1024 / geo.groups; if (nbg < 1) nbg = 1; if (nbg > ntiles) nbg = ntiles;
+    SS_CHECK(ws_bytes >= nbg * 10 * C * 4, "ss_dwconv3_bwd_fc2: workspace too small");
+    dim3 grid((unsigned)nbg, geo.groups);
+#define SS_DW_FC2(KS, DEPTH) hipLaunchKernelGGL((dwconv3_bwd_lane_kernel<1, KS, DEPTH>), grid, dim3(256), 0, stream, (const bf16*)dout, (const bf16*)x, w9c, bias, (bf16*)dx, workspace, B, H, W, C, geo, (const bf16*)w2t, keep)
+    if (K == 64) SS_DW_FC2(2, 3); else SS_DW_FC2(4, 3);
+#undef SS_DW_FC2
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(colreduce_final_kernel, dim3((unsigned)cdiv(10 * C, 8), 1), dim3(256), 0, stream, workspace, (int)nbg, 10 * C, 1.f, dw_db, 0);
     SS_LAUNCH_CHECK();

@@ -374,6 +374,30 @@ def dwconv3_bwd_fused(dy, x, w9c, bias, B, H, W, act=0):
     return dx, dwdb
 
 
+def dwconv3_bwd_fc2_ok(dout, x, B, H, W):
+    return bool(x.is_cuda and x.dtype == torch.bfloat16 and dout.dtype == x.dtype and dout.dim() == 2 and x.dim() == 2 and dout.is_contiguous()
+                and x.is_contiguous() and lib().ss_dwconv3_bwd_fc2_ok(dt(x), B, H, W, x.shape[1], dout.shape[1]))
+
+
+def dwconv3_bwd_fc2(dout, w2t, keep, x, w9c, bias, B, H, W):
+    """Mix-FFN backward from the gradient of fc2's output to the gradient of fc1's output: da2 = (dout @ w2t.T) * keep[image] stays on
+    chip.  dout [rows, K], w2t [C, K], x = fc1's output [rows, C].  -> dx [rows, C], dw_db [10, C] fp32."""
+    dev = _dev(x)
+    rows, C, ld = _mat(x, 'x')
+    K = dout.shape[1]
+    if ld != C or rows != B * H * W or dout.shape[0] != rows or tuple(w2t.shape) != (C, K) or w2t.dtype != x.dtype or not w2t.is_contiguous():
+        raise ValueError('dwconv3_bwd_fc2: bad x / dout / w2t')
+    _f32(w9c, 'w9c', 9 * C), _f32(bias, 'bias', C)
+    if keep is not None:
+        _f32(keep, 'keep', B)
+    dx = torch.empty_like(x)
+    dwdb = torch.empty((10, C), dtype=torch.float32, device=dev)
+    ws = workspace(dev, COLRED_BLOCKS * 10 * C * 4)
+    check(lib().ss_dwconv3_bwd_fc2(dt(x), _p(dout), _p(w2t), _p(keep), _p(x), _p(w9c), _p(bias), _p(dx), _p(dwdb), B, H, W, C, K,
+                                   _p(ws), ws.numel(), _stream()))
+    return dx, dwdb
+
+
 # ------------------------------------------------------------------ MiT attention
 def mit_attn_fwd(q, kv, B, N, Nk, heads, scale=None):
     """q [B*N, C], kv [B*Nk, 2C] -> o [B*N, C], lse [B, heads, round32(N)]."""

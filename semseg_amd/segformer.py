@@ -139,9 +139,20 @@ def mlp_forward(P, x, B, h, w, res=None, keep=None):
 def mlp_backward(P, S, dout, B, h, w, keep=None):
     T = dout.dtype
     G = {}
-    G['fc2.weight'], G['fc2.bias'], da2 = branch_head_grads(dout, S['a2'], w_bwd(P['fc2.weight'], T), keep, h * w)
-    Ch = da2.shape[1]
-    if h * w >= FUSED_DW_MIN_PIXELS:
+    Ch = S['h1'].shape[1]
+    if ops.dwconv3_bwd_fc2_ok(dout, S['h1'], B, h, w) and (keep is None or ops.gemm_tn_keep_ok(dout, S['a2'], h * w)):
+        # stages 1-2: fc2's data gradient inside the depthwise backward (da2, a [pixels, 4C] tensor, is never stored)
+        if keep is None:
+            G['fc2.weight'], G['fc2.bias'] = linear_grads(dout, S['a2'])
+        else:
+            G['fc2.weight'], G['fc2.bias'] = ops.gemm_tn_keep(dout, S['a2'], keep, h * w)
+        dh1, dwdb = ops.dwconv3_bwd_fc2(dout, w_bwd(P['fc2.weight'], T), keep, S['h1'], S['w9c'], P['dw_conv.dw_conv.bias'], B, h, w)
+        da2 = None
+    else:
+        G['fc2.weight'], G['fc2.bias'], da2 = branch_head_grads(dout, S['a2'], w_bwd(P['fc2.weight'], T), keep, h * w)
+    if da2 is None:
+        pass
+    elif h * w >= FUSED_DW_MIN_PIXELS:
         # one pass: dh1 and the tap / bias gradients together, g = da2 * GELU'(u) stays on chip (3 tensor passes instead of 5)
         dh1, dwdb = ops.dwconv3_bwd_fused(da2, S['h1'], S['w9c'], P['dw_conv.dw_conv.bias'], B, h, w, act=1)
     else:

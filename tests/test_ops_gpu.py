@@ -465,6 +465,36 @@ def test_dwconv3(ops, dtype, B, H, W, C):
         assert rel(dx2, dx) < 1e-2 and rel(dwdb2, dwdb) < 3e-3
 
 
+@pytest.mark.parametrize('keep', [False, True])
+@pytest.mark.parametrize('B,H,W,C,K', [(2, 40, 70, 256, 64), (3, 19, 33, 512, 128), (1, 64, 64, 64, 64), (2, 7, 5, 128, 128)])
+def test_dwconv3_bwd_with_fc2_data_gradient(ops, monkeypatch, B, H, W, C, K, keep):
+    """ss_dwconv3_bwd_fc2 == data-gradient GEMM of fc2 (rows scaled by DropPath) followed by the fused depthwise backward: the product
+    is rounded to bf16 where the GEMM stored it, so the two differ only by the summation order inside a 64 / 128-term dot product."""
+    T = torch.bfloat16
+    x, dout = dev(rnd(B * H * W, C), T), dev(rnd(B * H * W, K, seed=1), T)
+    w2t = dev(rnd(C, K, seed=2) / K ** 0.5, T)
+    w9c, b = dev(rnd(9, C, seed=3) / 3), dev(0.1 * rnd(C, seed=4))
+    kp = dev(torch.tensor([0.0, 1.25, 1.25][:B] if B > 1 else [1.25])) if keep else None
+    assert ops.dwconv3_bwd_fc2_ok(dout, x, B, H, W)
+    dx, dwdb = ops.dwconv3_bwd_fc2(dout, w2t, kp, x, w9c, b, B, H, W)
+    da2 = ops.gemm_nt(dout, w2t, rowscale=kp, rows_per_scale=H * W if keep else 0)
+    for lane in ('1', '0'):
+        monkeypatch.setenv('SS_DW_LANE', lane)
+        dx2, dwdb2 = ops.dwconv3_bwd_fused(da2, x, w9c, b, B, H, W, act=1)
+        assert rel(dx, dx2) < 4e-3 and rel(dwdb, dwdb2) < 2e-3
+    # and against autograd in fp32 on the bf16-rounded operands
+    xr = x.float().cpu().view(B, H, W, C).permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w9c.cpu().t().reshape(C, 1, 3, 3).clone().requires_grad_(True)
+    br = b.cpu().clone().requires_grad_(True)
+    dref = dout.float().cpu() @ w2t.float().cpu().t()
+    if keep:
+        dref = dref * kp.cpu().repeat_interleave(H * W)[:, None]
+    F.gelu(F.conv2d(xr, wr, br, padding=1, groups=C)).backward(dref.view(B, H, W, C).permute(0, 3, 1, 2))
+    assert rel(dx.view(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < _gtol(T)
+    assert rel(dwdb[:9].t().reshape(C, 1, 3, 3), wr.grad) < _gtol(T)
+    assert rel(dwdb[9], br.grad) < _gtol(T)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,N,Nk,heads,D', [(2, 256, 4, 1, 32), (1, 1000, 100, 2, 64), (2, 64, 64, 5, 32), (1, 96, 256, 8, 64), (1, 33, 1, 1, 64)])
 def test_mit_attention(ops, dtype, B, N, Nk, heads, D):
