@@ -619,14 +619,15 @@ __global__ __launch_bounds__(256, 2) void dwconv3_bwd_lane_kernel(const bf16* __
 #pragma unroll
         for (int s = 0; s < KS; ++s) wfs[s][tid] = *(const bf16x8*)(wr + 32 * s);
     }
-    __shared__ bf16x8 bst[KS > 0 ? 4 * 3 * KS : 1][64];       // [wave][ring slot][s][lane]
+    constexpr int NB = KS > 0 ? KS : 1;                       // fills per row of the dy / dout queue
+    __shared__ bf16x8 bst[4 * 3 * NB][64];                    // [wave][ring slot][s][lane]; KS = 0: the dy row, laid out like the x row
     constexpr int XSLOT = 640;                                // bytes per x slot: 36 lanes x 16, rounded up
-    __shared__ __attribute__((aligned(16))) char xq[KS > 0 ? 4 * 3 * XSLOT : 16];       // [wave][ring slot][lane]
-    __shared__ float shf_own[KS > 0 ? 1 : 256 * NE];
-    float* shf = KS > 0 ? (float*)&bst[0][0] : shf_own;      // the final combine reuses the dout queue (drained first)
+    __shared__ __attribute__((aligned(16))) char xq[4 * 3 * XSLOT];                     // [wave][ring slot][lane]
+    float* shf = (float*)&bst[0][0];                          // the final combine reuses the dy / dout queue (drained first)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const unsigned bbase = lds_addr(&bst[wave * 3 * KS][0]), xbase = lds_addr(xq + (KS > 0 ? wave * 3 * XSLOT : 0));
-    const V* xqw = (const V*)(xq + (KS > 0 ? wave * 3 * XSLOT : 0));     // XSLOT / 8 V per slot: centre of lane (xs, kg) at xs * 4 + kg, edge columns from 64
+    const unsigned bbase = lds_addr(&bst[wave * 3 * NB][0]), xbase = lds_addr(xq + wave * 3 * XSLOT);
+    const V* xqw = (const V*)(xq + wave * 3 * XSLOT);         // XSLOT / 8 V per slot: centre of lane (xs, kg) at xs * 4 + kg, edge columns from 64
+    const V* dqw = (const V*)&bst[wave * 3 * NB][0];          // KS = 0: 128 V per slot, same order
     const int xci = xs * 4 + kg, xoi = 64 + (xs == 15 ? 4 : 0) + kg;
     const int tiles_per_img = g.xtiles * g.ystrips, ntiles = B * tiles_per_img;
     const int64_t rs = (int64_t)W * C, rsd = (int64_t)W * (KS > 0 ? K : C);
@@ -645,19 +646,17 @@ __global__ __launch_bounds__(256, 2) void dwconv3_bwd_lane_kernel(const bf16* __
         const int rb = max(y0 - 1, 0);                           // row the base pointers stand on
         const int64_t pix = ((int64_t)img * H + rb) * W + xc, off = pix * C + c;
         const bf16* px = x + off;
-        const bf16* pd = KS > 0 ? dy + pix * K + 8 * kg : dy + off;
+        const bf16* pd = dy + pix * K + 8 * kg;
         bf16* po = dxo + off;
         const float kscale = (KS > 0 && keep) ? keep[img] : 1.f;
         const int r0 = y0 - 1;
         // the fill lane's own address: 16 bytes of a centre pixel (lanes 0 .. 31) or of an edge column (32 .. 35)
-        const bf16* pq = x;
-        if (KS > 0) {
-            const int t0 = (rem % g.xtiles) * 14 - 1;
-            const int qc = lane < 32 ? t0 + (lane >> 1) : (lane < 34 ? t0 - 1 : t0 + 16);
-            pq = x + (((int64_t)img * H + rb) * W + min(max(qc, 0), W - 1)) * C + blockIdx.y * 64 + wave * 16 + (lane & 1) * 8;
-        }
+        const int t0 = (rem % g.xtiles) * 14 - 1;
+        const int qc = lane < 32 ? t0 + (lane >> 1) : (lane < 34 ? t0 - 1 : t0 + 16);
+        const int64_t qoff = (((int64_t)img * H + rb) * W + min(max(qc, 0), W - 1)) * C + blockIdx.y * 64 + wave * 16 + (lane & 1) * 8;
+        const bf16* pq = x + qoff;
+        if (KS == 0) pd = dy + qoff;                              // dy rows are fetched like x rows (lanes 0 .. 31)
         float win[3][3][NE], gw[3][3][NE];
-        V ring[3][2], dring[KS > 0 ? 1 : 3];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -678,18 +677,15 @@ __global__ __launch_bounds__(256, 2) void dwconv3_bwd_lane_kernel(const bf16* __
             for (int j = 0; j < 3; ++j) {
                 const int64_t xo = (int64_t)(min(max(r0 + 2 + j, 0), ylast) - rb) * rs;
                 const bf16* q = pd + (int64_t)(min(max(r0 + j, 0), dlast) - rb) * rsd;
-                if (KS == 0) {
-                    ring[(2 + j) % 3][0] = raw_load<bf16, NE>(px + xo); ring[(2 + j) % 3][1] = raw_load<bf16, NE>(px + xo + offO);
-                    dring[j] = raw_load<bf16, NE>(q);
-                } else {
-                    if (lane < 36) dwl_dma(pq + xo, xbase + ((2 + j) % 3) * XSLOT, 0u);
+                if (lane < 36) dwl_dma(pq + xo, xbase + ((2 + j) % 3) * XSLOT, 0u);
+                if (KS == 0) { if (lane < 32) dwl_dma(q, bbase + j * 1024, 0u); }
+                else {
 #pragma unroll
                     for (int s = 0; s < KS; ++s) dwl_dma(q + 32 * s, bbase + (j * KS + s) * 1024, 0u);
                 }
             }
         }
         const int nsteps = yend - y0 + 3;                        // rows y0-1 .. yend of g, and one more step: dx trails g by two rows
-        if (KS == 0) DW_DRAIN_PROLOGUE();
         constexpr int UNR = 3;
         for (int s0 = 0; s0 < nsteps; s0 += UNR) {
 #pragma unroll
@@ -697,18 +693,15 @@ __global__ __launch_bounds__(256, 2) void dwconv3_bwd_lane_kernel(const bf16* __
                 const int r = r0 + s0 + i;                        // the row of g this step produces
                 float u[NE], go[NE];
                 union { V v; unsigned w[NE / 2]; } d;
+                dwl_wait<2 + 2 * NB>();                             // the dy / dout row issued three steps ago: two steps of [x, NB fills] since
                 if (KS > 0) {
                     floatx4 a4 = {0.f, 0.f, 0.f, 0.f};
-                    dwl_wait<2 + 2 * KS>();                         // the dout row issued three steps ago: two steps of [x, dout x KS] since
 #pragma unroll
                     for (int s = 0; s < KS; ++s)
                         a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfs[s][tid], bst[(wave * 3 + i % 3) * KS + s][lane], a4, 0, 0, 0);
 #pragma unroll
                     for (int e = 0; e < NE; ++e) d.v[e] = (bf16)(a4[e] * kscale);       // da2 as the GEMM would have stored it
-                } else {
-                    d.v = dring[i % 3];
-                    dring[i % 3] = raw_load<bf16, NE>(pd + (int64_t)(min(max(r + 3, 0), dlast) - rb) * rsd);
-                }
+                } else d.v = dqw[(i % 3) * 128 + xci];
                 dw_taps<NE>(win[i % 3], win[(i + 1) % 3], win[(i + 2) % 3], wt, bv, u);
                 const unsigned live = (r >= 0 && r <= dlast && r <= yend && colok) ? ~0u : 0u;     // g is zero outside the image
 #pragma unroll
@@ -760,16 +753,14 @@ __global__ __launch_bounds__(256, 2) void dwconv3_bwd_lane_kernel(const bf16* __
                     } }
                 const unsigned k = r + 2 < H ? ~0u : 0u;          // r + 2 >= y0 + 1 > 0
                 const int64_t xo = (int64_t)(min(max(r + 5, 0), ylast) - rb) * rs;
-                if (KS == 0) {
-                    dwl_cvt_row<NE>(ring[(i + 2) % 3], mC & k, mO & k, win[i % 3]);
-                    ring[(i + 2) % 3][0] = raw_load<bf16, NE>(px + xo); ring[(i + 2) % 3][1] = raw_load<bf16, NE>(px + xo + offO);
-                } else {
-                    dwl_wait<2 + 3 * KS>();                         // the x row issued three steps ago, its dout rows and two whole steps since
-                    union { V v[2]; unsigned w[NE]; } xr;
-                    xr.v[0] = xqw[((i + 2) % 3) * (XSLOT / 8) + xci]; xr.v[1] = xqw[((i + 2) % 3) * (XSLOT / 8) + xoi];
-                    dwl_cvt_row<NE>(xr.v, mC & k, mO & k, win[i % 3]);
-                    if (lane < 36) dwl_dma(pq + xo, xbase + ((i + 2) % 3) * XSLOT, xr.w[0] | xr.w[2]);
-                    const bf16* q = pd + (int64_t)(min(max(r + 3, 0), dlast) - rb) * rsd;
+                dwl_wait<2 + 3 * NB>();                             // the x row issued three steps ago, the NB fills after it and two whole steps since
+                union { V v[2]; unsigned w[NE]; } xr;
+                xr.v[0] = xqw[((i + 2) % 3) * (XSLOT / 8) + xci]; xr.v[1] = xqw[((i + 2) % 3) * (XSLOT / 8) + xoi];
+                dwl_cvt_row<NE>(xr.v, mC & k, mO & k, win[i % 3]);
+                if (lane < 36) dwl_dma(pq + xo, xbase + ((i + 2) % 3) * XSLOT, xr.w[0] | xr.w[2]);
+                const bf16* q = pd + (int64_t)(min(max(r + 3, 0), dlast) - rb) * rsd;
+                if (KS == 0) { if (lane < 32) dwl_dma(q, bbase + (i % 3) * 1024, d.w[0]); }
+                else {
 #pragma unroll
                     for (int s = 0; s < KS; ++s) dwl_dma(q + 32 * s, bbase + ((i % 3) * KS + s) * 1024, d.w[0]);
                 }
@@ -777,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3_bwd_lane_kernel(const bf16* __
         }
     }
     // combine the column lanes of each chunk lane through LDS in a fixed order
-    if (KS > 0) dwl_wait<0>();                                // fills issued past the last strip still land in the queue the combine reuses
+    dwl_wait<0>();                                            // fills issued past the last strip still land in the queue the combine reuses
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
         __syncthreads();
@@ -880,6 +871,9 @@ extern "C" int ss_dwconv3_bwd_fc2_ok(int dtype, int B, int H, int W, int C, int 
     if (dtype != SS_BF16 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 64 || !(K == 64 || K == 128)) return 0;
     const char* e = getenv("SS_DW_FC2");
     if (e && e[0] == '0') return 0;
+    // K = 128 (MiT stage 2) is built and tested but loses to GEMM + lane kernel (493 against 444 us per block: four dout fills and eight
+    // fragment reads per wave and row, and 80 KB of LDS per workgroup); SS_DW_FC2=2 runs it anyway
+    if (K == 128 && !(e && e[0] == '2')) return 0;
     return dwl_ok(dwf_geom(B, H, W, C, 4), C) ? 1 : 0;
 }
 extern "C" int ss_dwconv3_bwd_fc2(int dtype, const void* dout, const void* w2t, const float* keep, const void* x, const float* w9c, const float* bias,

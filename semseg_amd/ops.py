@@ -4,6 +4,8 @@ Every function validates shapes / dtypes / contiguity on the host, borrows the t
 asynchronous launch on the current torch HIP stream and returns torch tensors.  PyTorch is used for allocation only.
 There is no fallback: tensors must live on a HIP device and the library must be built.
 """
+import os
+
 import torch
 from ._lib import lib, check
 
@@ -372,6 +374,11 @@ def dwconv3_bwd_fused(dy, x, w9c, bias, B, H, W, act=0):
     ws = workspace(dev, COLRED_BLOCKS * 10 * C * 4)
     check(lib().ss_dwconv3_bwd_fused(dt(x), _p(dy), _p(x), _p(w9c), _p(bias), _p(dx), _p(dwdb), B, H, W, C, act, _p(ws), ws.numel(), _stream()))
     return dx, dwdb
+
+
+def dwconv3_lane_ok(x):
+    """True where ss_dwconv3_bwd_fused runs its lane-per-column kernel (dwl_ok in dwconv.hip)."""
+    return bool(x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] % 64 == 0 and os.environ.get('SS_DW_LANE', '1')[:1] != '0')
 
 
 def dwconv3_bwd_fc2_ok(dout, x, B, H, W):

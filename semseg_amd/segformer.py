@@ -116,6 +116,9 @@ def attn_backward(P, S, dout, B, h, w, head, sr, keep=None):
 FUSED_DW_MIN_PIXELS = 4096        # maps at least this large take the one-pass depthwise backward (measured crossover: 32 x 32 loses, 64 x 64 wins)
 
 
+FUSED_DW_LANE_MIN_PIXELS = 1024   # the lane-per-column kernel (bf16, C % 64 == 0) has no barrier in its row loop: 32 x 32 wins as well (132 against 170 us)
+
+
 FUSED_MIXFFN = True               # C = 64 / 128 in bf16 (MiT stages 1-2): fc1 -> depthwise + GELU -> fc2 as ONE kernel, hidden tensors on chip
 
 
@@ -152,7 +155,7 @@ def mlp_backward(P, S, dout, B, h, w, keep=None):
         G['fc2.weight'], G['fc2.bias'], da2 = branch_head_grads(dout, S['a2'], w_bwd(P['fc2.weight'], T), keep, h * w)
     if da2 is None:
         pass
-    elif h * w >= FUSED_DW_MIN_PIXELS:
+    elif h * w >= (FUSED_DW_LANE_MIN_PIXELS if ops.dwconv3_lane_ok(S['h1']) else FUSED_DW_MIN_PIXELS):
         # one pass: dh1 and the tap / bias gradients together, g = da2 * GELU'(u) stays on chip (3 tensor passes instead of 5)
         dh1, dwdb = ops.dwconv3_bwd_fused(da2, S['h1'], S['w9c'], P['dw_conv.dw_conv.bias'], B, h, w, act=1)
     else:

@@ -475,6 +475,7 @@ def test_dwconv3_bwd_with_fc2_data_gradient(ops, monkeypatch, B, H, W, C, K, kee
     w2t = dev(rnd(C, K, seed=2) / K ** 0.5, T)
     w9c, b = dev(rnd(9, C, seed=3) / 3), dev(0.1 * rnd(C, seed=4))
     kp = dev(torch.tensor([0.0, 1.25, 1.25][:B] if B > 1 else [1.25])) if keep else None
+    monkeypatch.setenv('SS_DW_FC2', '2')             # K = 128 is off by default (slower than GEMM + depthwise backward there)
     assert ops.dwconv3_bwd_fc2_ok(dout, x, B, H, W)
     dx, dwdb = ops.dwconv3_bwd_fc2(dout, w2t, kp, x, w9c, b, B, H, W)
     da2 = ops.gemm_nt(dout, w2t, rowscale=kp, rows_per_scale=H * W if keep else 0)
