@@ -564,6 +564,13 @@ __device__ __forceinline__ float lane_left(float v, float edge) {    // value of
 __device__ __forceinline__ float lane_right(float v, float edge) {   // value of lane + 1; lane 15 receives `edge`
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
 }
+// the same with zero beyond the row of 16 (no register to preset)
+__device__ __forceinline__ float lane_left0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_right0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+}
 template <int NE>
 __device__ __forceinline__ void dwl_cvt_row(const vecn<bf16, NE> (&raw)[2], unsigned keepC, unsigned keepO, float (&row)[3][NE]) {
     union { vecn<bf16, NE> v; unsigned u[NE / 2]; } c, o;
@@ -739,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3_bwd_lane_kernel(const bf16* __
                 }
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {                    // slot of row r-3 is free now: row r moves in, with its neighbours
-                    gw[i % 3][1][e] = go[e]; gw[i % 3][0][e] = lane_left(go[e], 0.f); gw[i % 3][2][e] = lane_right(go[e], 0.f);
+                    gw[i % 3][1][e] = go[e]; gw[i % 3][0][e] = lane_left0(go[e]); gw[i % 3][2][e] = lane_right0(go[e]);
                 }
                 // weight / bias gradient: own rows and own columns only (halo g belongs to the neighbouring workgroup)
                 const float own = (inner && r >= y0 && r < yend) ? 1.f : 0.f;
