@@ -175,7 +175,8 @@ int ss_dwconv3_bwd(int dtype, const void* dy, const void* x, const float* w9c, c
                    int B, int H, int W, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
 /* The backward in ONE pass (3 tensor passes instead of 5): dx = the gradient of the dwconv input, dw_db as above; g never reaches
- * memory (column neighbours exchange it through LDS, rounded to the storage dtype as the stored g is).  dx must not alias dy / x. */
+ * memory (column neighbours exchange it through DPP lane shifts -- bf16 with C % 64 == 0 -- or through LDS, rounded to the storage
+ * dtype as the stored g is; both kernels give the same bits).  dx must not alias dy / x. */
 int ss_dwconv3_bwd_fused(int dtype, const void* dy, const void* x, const float* w9c, const float* bias, void* dx, float* dw_db,
                          int B, int H, int W, int C, int act, float* workspace, int64_t ws_bytes, hipStream_t stream);
 
