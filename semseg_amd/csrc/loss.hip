@@ -68,13 +68,27 @@ __device__ __forceinline__ void load_pixel(const T* __restrict__ p, int C, bool 
         for (int c = 0; c < 8; ++c) if (c < C) v[c] = to_f(p[c]);
     }
 }
+// A thread keeps CE_UNR pixels in flight (all their loads are issued before the first is reduced): with one pixel per iteration the
+// 20 bytes a lane has outstanding leave the kernel latency-bound at 2 TB/s.  Per-pixel arithmetic and the order of every sum are unchanged.
+#define CE_UNR 4
 template <typename T>
 __global__ __launch_bounds__(256) void ce_prob_cl_kernel(const T* __restrict__ logits, int64_t pitch, const long long* __restrict__ labels,
         float* __restrict__ prob, float* __restrict__ nll, unsigned* __restrict__ vkey, OhemCtl* ctl, int64_t npix, int C, long long ignore, int pairs) {
     long long nv = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
-        float v[8]; load_pixel(logits + i * pitch, C, pairs != 0, v);
-        const long long lab = labels[i];
+    const int64_t S = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < npix; i0 += CE_UNR * S) {
+      float vv[CE_UNR][8]; long long labv[CE_UNR];
+#pragma unroll
+      for (int u = 0; u < CE_UNR; ++u) {
+          const int64_t ii = min(i0 + u * S, npix - 1);          // clamped: the loads stay unconditional
+          load_pixel(logits + ii * pitch, C, pairs != 0, vv[u]); labv[u] = labels[ii];
+      }
+#pragma unroll
+      for (int u = 0; u < CE_UNR; ++u) {
+        const int64_t i = i0 + u * S;
+        if (i >= npix) break;
+        float (&v)[8] = vv[u];
+        const long long lab = labv[u];
         float mx = v[0];
 #pragma unroll
         for (int c = 1; c < 8; ++c) mx = fmaxf(mx, v[c]);
@@ -86,6 +100,7 @@ __global__ __launch_bounds__(256) void ce_prob_cl_kernel(const T* __restrict__ l
         const bool valid = lab != ignore;
         prob[i] = pr; nll[i] = nl; vkey[i] = valid ? __float_as_uint(pr) : 0xFFFFFFFFu;
         nv += valid;
+      }
     }
     __shared__ long long sh[256];
     sh[threadIdx.x] = nv; __syncthreads();
@@ -151,9 +166,14 @@ __global__ __launch_bounds__(256) void ohem_hist_kernel(const unsigned* __restri
     __syncthreads();
     int shift; unsigned mask, himask; pass_bits(pass, shift, mask, himask);
     const unsigned prefix = ctl->prefix;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned key = vkey[i];
-        if (key != 0xFFFFFFFFu && (key & himask) == prefix) atomicAdd(&sh[(key >> shift) & mask], 1u);
+    const int64_t S = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < npix; i0 += CE_UNR * S) {
+        unsigned key[CE_UNR];
+#pragma unroll
+        for (int u = 0; u < CE_UNR; ++u) key[u] = i0 + u * S < npix ? vkey[i0 + u * S] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < CE_UNR; ++u)
+            if (key[u] != 0xFFFFFFFFu && (key[u] & himask) == prefix) atomicAdd(&sh[(key[u] >> shift) & mask], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < OHEM_BINS; i += blockDim.x) if (sh[i]) atomicAdd(&hist[i], sh[i]);
@@ -259,9 +279,19 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict_
     const int sel = ctl->do_select; const float thr = ctl->thr;
     float s = 0.f; unsigned n = 0;
     const int64_t per = cdiv(npix, gridDim.x), beg = blockIdx.x * per, end = min(npix, beg + per);
-    for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
-        const bool keep = vkey[i] != 0xFFFFFFFFu && (!sel || prob[i] < thr);
-        if (keep) { s += nll[i]; ++n; }
+    // a valid pixel's key IS its probability's bit pattern (ce_prob_*_kernel): `prob` is not read again
+    for (int64_t i0 = beg + threadIdx.x; i0 < end; i0 += CE_UNR * 256) {
+        unsigned key[CE_UNR]; float nl[CE_UNR];
+#pragma unroll
+        for (int u = 0; u < CE_UNR; ++u) {
+            const int64_t i = i0 + u * 256;
+            key[u] = i < end ? vkey[i] : 0xFFFFFFFFu; nl[u] = i < end ? nll[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < CE_UNR; ++u) {
+            const bool keep = key[u] != 0xFFFFFFFFu && (!sel || __uint_as_float(key[u]) < thr);
+            if (keep) { s += nl[u]; ++n; }
+        }
     }
     __shared__ float ss[256]; __shared__ unsigned sn[256];
     ss[threadIdx.x] = s; sn[threadIdx.x] = n; __syncthreads();
