@@ -154,6 +154,11 @@ def entry_work(name, a):
         return 'hbm', 28.0 * a[4]
     if name == 'ss_dwconv3_bwd_fused':
         return 'hbm', 3.0 * a[7] * a[8] * a[9] * a[10] * _sz(a[0])
+    if name == 'ss_dwconv3_bwd_fc2':     # (dtype, dout, w2t, keep, x, w9c, bias, dx, dw_db, B, H, W, C, K, ...): x in, dx out, dout in; da2 stays on chip
+        return 'hbm', 1.0 * a[9] * a[10] * a[11] * (2 * a[12] + a[13]) * _sz(a[0])
+    if name == 'ss_mixffn_fwd':          # (dtype, x, w1, b1, w9, bd, w2, b2, res, keep, out, h1_out, a2_out, B, H, W, C, Ch): x (+ res) in, out, and the two
+        B, H, W, C, Ch = a[13:18]        # hidden tensors out when the backward will read them; the products cost a tenth of that on the matrix cores
+        return 'hbm', 1.0 * B * H * W * ((2 + (1 if a[8] else 0)) * C + (2 * Ch if a[11] else 0)) * _sz(a[0])
     if name == 'ss_rowscale':
         return 'hbm', 2.0 * a[5] * a[6] * _sz(a[0])
     if name in ('ss_lawin_attn_fwd', 'ss_lawin_attn_bwd'):          # window attention: HBM-bound at these head dims (64 keys per window)
